@@ -1,0 +1,209 @@
+/* nbody_hip.h -- C ABI of libnbody_hip.so: the gravity step of JMS55/nbody on MI355X (gfx950).
+ *
+ * The reference exposes no library, plugin or FFI interface (Cargo.toml:6-16 declares three
+ * binaries).  Its only stable contract for this path is the GPU buffer layout its compute passes
+ * bind and the per-frame step sequence.  Each entry point below names the reference code it
+ * replaces.  Buffers keep the reference's layouts:
+ *   masses                f32[N]                       src/nbody.wgsl:1
+ *   positions/velocities/accelerations
+ *                         f32[N][4], xyz + 4-byte pad  src/nbody.wgsl:3-8 (vec3 stride 16)
+ *   octree                96-byte nodes                src/nbodybh.wgsl:1-9,26
+ *
+ * Conventions: every function returns 0 on success and a negative nbody_status on failure;
+ * nbody_last_error(ctx) returns a message.  Nothing aborts.  A context is not thread-safe (the
+ * reference steps from one thread).  Steps are enqueued asynchronously on the context's HIP
+ * stream; nbody_download*, nbody_sync, nbody_energy and nbody_counters block.  All pointers named
+ * host_* are host memory; pointers returned by nbody_device_buffer are device memory.
+ */
+#ifndef NBODY_HIP_H
+#define NBODY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nbody_ctx nbody_ctx;
+
+enum nbody_status {
+    NBODY_OK = 0,
+    NBODY_ERR_INVALID = -1,   /* bad argument */
+    NBODY_ERR_HIP = -2,       /* a HIP runtime call failed */
+    NBODY_ERR_NO_DEVICE = -3, /* no usable gfx950 device */
+    NBODY_ERR_STATE = -4,     /* call made in the wrong state (e.g. step before upload) */
+    NBODY_ERR_CAPACITY = -5,  /* a fixed capacity was exceeded (tree nodes, traversal stack) */
+    NBODY_ERR_NOMEM = -6
+};
+
+/* Force law of one source term on a target at pos with velocity vel; d = p_j - pos. */
+enum nbody_law {
+    /* src/nbody_cpu.rs:337-340: G*m_j*d / (d.d)^3, self skipped, no softening. */
+    NBODY_LAW_CPU_R6 = 0,
+    /* src/nbody.wgsl:54-81: G*m_j*d / (|d|^2+eps2)^1.5 * acos(vel.d/(|d||vel|+1))^0.15, self included. */
+    NBODY_LAW_WGSL_BIAS = 1,
+    /* The WGSL law without the bias factor (Plummer-softened Newtonian gravity). */
+    NBODY_LAW_PLUMMER = 2
+};
+
+enum nbody_integrator {
+    /* src/nbody_cpu.rs:345-348,358-360: acc2=a; vel2+=a; pos2+=vel2; swap sets (two interleaved states). */
+    NBODY_INT_CPU_EULER_XBUF = 0,
+    /* src/nbody.wgsl:132-138: pos+=vel*dt+0.5*acc_in*dt^2; vel+=0.5*(acc_in+acc)*dt. */
+    NBODY_INT_WGSL_VERLET = 1
+};
+
+/* Node types of src/octree_maxdepth.rs:8-11. */
+enum nbody_node_type { NBODY_NODE_DUMMY = 0, NBODY_NODE_LEAFBODY = 1, NBODY_NODE_LEAFLIST = 2, NBODY_NODE_INTERIOR = 3 };
+
+/* src/octree_maxdepth.rs:13-23 in the storage layout of src/nbodybh.wgsl:1-9 (96 bytes).
+ * child_indices[k]==0 means "no child" (the root, index 0, is never a child).  For a LEAFLIST
+ * node child_indices[0] is the first list member and child_indices[1] the member count
+ * (src/octree_maxdepth.rs:53-54). */
+typedef struct nbody_octree_node {
+    float center_of_mass[3];
+    float _pad0;
+    float pos_min[3];
+    float _pad1;
+    float pos_max[3];
+    float range; /* longest side of the bodies' bounding box (src/octree_maxdepth.rs:101) */
+    float total_mass;
+    uint32_t child_indices[8];
+    uint32_t node_type;
+    uint32_t depth; /* padding in the reference (max_depth in src/octree.rs:14); here the node's depth */
+    uint32_t _pad2;
+} nbody_octree_node;
+
+/* Compile-time constants of the reference gathered in one struct.  nbody_config_default fills the
+ * reference's values: G, dt, eps2 (src/nbody.wgsl:13-15), theta (src/nbodybh.wgsl:61),
+ * world (src/nbody_gpu.rs:15), max_depth (src/octree_maxdepth.rs:7). */
+typedef struct nbody_config {
+    uint64_t n_bodies;     /* N over all shards */
+    int32_t law;           /* enum nbody_law */
+    int32_t integrator;    /* enum nbody_integrator */
+    float G;               /* 0.0066743 (CPU_R6 always uses this literal, as the reference does) */
+    float dt;              /* 0.1 */
+    float eps2;            /* 1.0 */
+    float theta;           /* 0.5 */
+    float world;           /* 250.0: octree root cube [0,world]^3 and the Barnes-Hut clamp box */
+    uint32_t max_depth;    /* 1..16 octree depth cap */
+    int32_t leaflist_mode; /* 0: literal src/octree_maxdepth.rs:123-133 (a k-body list holds the k-1 prefix
+                              aggregates); 1: every body of the cell is a list member */
+    uint64_t shard_begin;  /* first target body integrated by this context */
+    uint64_t shard_count;  /* number of target bodies integrated by this context (0 => all) */
+    int32_t device;        /* HIP device ordinal, -1 = current device */
+    int32_t reserved;
+    void* stream;          /* hipStream_t to enqueue on, NULL = a stream owned by the context */
+} nbody_config;
+
+/* Device buffers a host may need to reach (for the per-step all-gather between shards). */
+enum nbody_buffer {
+    NBODY_BUF_POSM = 0,  /* current positions, f32[N][4]; the pad lane carries the body's mass */
+    NBODY_BUF_VEL = 1,   /* current velocities f32[N][4] */
+    NBODY_BUF_ACC = 2,   /* current accelerations f32[N][4] */
+    NBODY_BUF_OCTREE = 3 /* nbody_octree_node[n_nodes] after nbody_export_octree */
+};
+
+/* Work done since nbody_create or the last nbody_counters_reset; for roofline arithmetic. */
+typedef struct nbody_counters_t {
+    uint64_t steps_allpairs;
+    uint64_t steps_bh;
+    uint64_t interactions_allpairs; /* body-body terms evaluated */
+    uint64_t bh_node_visits;        /* per-body node visits of the last counted walk */
+    uint64_t bh_leaf_interactions;
+    uint64_t bh_aggregate_interactions;
+    uint64_t bh_wave_node_visits;   /* per-wavefront node visits of the last counted walk */
+    uint64_t octree_nodes;          /* nodes of the last built tree */
+    uint64_t bh_max_stack;          /* deepest traversal stack of the last counted walk */
+    uint64_t reserved[7];
+} nbody_counters_t;
+
+const char* nbody_version(void);
+/* Message of the last failing call on ctx (or on creation when ctx is NULL). */
+const char* nbody_last_error(const nbody_ctx* ctx);
+
+void nbody_config_default(nbody_config* cfg);
+
+/* Replaces device/buffer/pipeline setup, src/nbody_gpu.rs:83-309. */
+int nbody_create(nbody_ctx** out, const nbody_config* cfg);
+void nbody_destroy(nbody_ctx* ctx);
+
+/* Replaces the create_buffer_init calls of src/nbody_gpu.rs:85-143.  host_pos16 is f32[N][4].
+ * host_vel16 / host_acc16 may be NULL => zeros (the reference's initial state, :122-137). */
+int nbody_upload(nbody_ctx* ctx, const float* host_masses, const float* host_pos16, const float* host_vel16,
+                 const float* host_acc16);
+/* Second buffer set of the CPU binary (src/nbody_cpu.rs:58-60); NULL pointers => zeros, which is
+ * also what nbody_upload leaves there. Only read by NBODY_INT_CPU_EULER_XBUF. */
+int nbody_upload_alt(nbody_ctx* ctx, const float* host_pos16, const float* host_vel16, const float* host_acc16);
+
+/* Replaces one MainEventsCleared tick of src/nbody_gpu.rs:418-451 (or of src/nbody_cpu.rs:319-360
+ * with NBODY_INT_CPU_EULER_XBUF), nsteps times: forces over all N sources for this context's
+ * targets, integration, swap of the in/out sets.  With shard_count < N only nsteps == 1 is
+ * accepted: the host must all-gather NBODY_BUF_POSM between steps. */
+int nbody_step_allpairs(nbody_ctx* ctx, int nsteps);
+/* Replaces one tick of src/nbody_gpu_bh.rs:445-527: octree build from the current positions,
+ * traversal, integration with clamp to [0,world]^3, swap. */
+int nbody_step_bh(nbody_ctx* ctx, int nsteps);
+
+/* Forces only (no integration, no swap), for parity checks against src/nbody.wgsl:50-116 and
+ * src/nbodybh.wgsl:63-161.  host_acc16_out is f32[N][4]; only this context's targets are written. */
+int nbody_accel_allpairs(nbody_ctx* ctx, float* host_acc16_out);
+/* Uses the tree currently held by the context (built or uploaded). */
+int nbody_accel_bh(nbody_ctx* ctx, float* host_acc16_out);
+
+/* Replaces OctreeNode::new_tree, src/octree_maxdepth.rs:26-61 (called at src/nbody_gpu_bh.rs:452). */
+int nbody_build_octree(nbody_ctx* ctx);
+/* Writes the current tree in the 96-byte layout.  cap_nodes: capacity of host_nodes; *n_nodes
+ * receives the node count (also when host_nodes is NULL, to size the buffer). */
+int nbody_download_octree(nbody_ctx* ctx, nbody_octree_node* host_nodes, uint64_t cap_nodes, uint64_t* n_nodes);
+/* Replaces the per-frame octree upload of src/nbody_gpu_bh.rs:454-469: traversals use this tree
+ * (any child numbering, e.g. the reference's allocation order) until the next build. */
+int nbody_upload_octree(nbody_ctx* ctx, const nbody_octree_node* host_nodes, uint64_t n_nodes);
+/* Per body: the 3*max_depth-bit Morton key of its depth-max_depth cell (octant bits x->4, y->2,
+ * z->1 per level, src/octree_maxdepth.rs:210-222), the depth of its leaf in the built tree, and
+ * the sorted order (body index of rank r).  Any pointer may be NULL.  Requires a built tree. */
+int nbody_morton_keys(nbody_ctx* ctx, uint64_t* host_keys, uint8_t* host_leaf_depth, uint32_t* host_order);
+
+/* Replaces the position readback of src/nbody_gpu_bh.rs:496-516 (and extends it to all state).
+ * Any pointer may be NULL.  The pad lane of host_pos16 is written as 0. */
+int nbody_download(nbody_ctx* ctx, float* host_pos16, float* host_vel16, float* host_acc16);
+int nbody_download_alt(nbody_ctx* ctx, float* host_pos16, float* host_vel16, float* host_acc16);
+int nbody_sync(nbody_ctx* ctx);
+/* Kinetic and softened potential energy of the current state, accumulated in f64 on the device
+ * (all-pairs; O(N^2)).  No counterpart in the reference; used for the 1000-step drift check. */
+int nbody_energy(nbody_ctx* ctx, double* kinetic, double* potential);
+int nbody_counters(nbody_ctx* ctx, nbody_counters_t* out);
+int nbody_counters_reset(nbody_ctx* ctx);
+/* When on, the next nbody_accel_bh / nbody_step_bh uses the counting traversal (slower). */
+int nbody_set_counting(nbody_ctx* ctx, int on);
+
+/* Device pointer and size of one of the context's current buffers (enum nbody_buffer), for hosts
+ * that exchange shards themselves (RCCL all-gather of NBODY_BUF_POSM).  No counterpart in the
+ * reference (it is single-device). */
+int nbody_device_buffer(nbody_ctx* ctx, int which, void** dev_ptr, size_t* bytes);
+/* The hipStream_t the context enqueues on. */
+void* nbody_stream(nbody_ctx* ctx);
+/* Average duration in milliseconds of the dominant kernel (all-pairs force kernel, or the
+ * Barnes-Hut traversal kernel) over the launches since the last call, measured with HIP events on
+ * the context's stream; *launches receives their count.  Blocks. */
+int nbody_kernel_time(nbody_ctx* ctx, int bh, double* avg_ms, uint64_t* launches);
+int nbody_set_kernel_timing(nbody_ctx* ctx, int on);
+
+/* Synthetic initial conditions (host code, no GPU).  Counter-based splitmix64 stream: draw k of
+ * body i is mix64(seed + (64*i + k + 1) * 0x9E3779B97F4A7C15), u = (x >> 40) * 2^-24.
+ * refcube follows src/nbody_gpu.rs:61-81: pos uniform in [world/5, 4*world/5)^3,
+ * mass = U[0.5,8]*U[0.5,8], zero velocity.  first/count select a body range. */
+int nbody_gen_refcube(uint64_t seed, uint64_t first, uint64_t count, float world, float* host_masses,
+                      float* host_pos16);
+/* Plummer sphere centred in the world cube, scale radius a, radius cut rmax, equal masses
+ * total_mass/n_total.  host_vel16 may be NULL; otherwise velocities are zero (equilibrium == 0) or
+ * drawn from the Aarseth-Henon-Wielen distribution for gravitational constant G. */
+int nbody_gen_plummer(uint64_t seed, uint64_t first, uint64_t count, uint64_t n_total, float world, float a,
+                      float rmax, float total_mass, float G, int equilibrium, float* host_masses,
+                      float* host_pos16, float* host_vel16);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBODY_HIP_H */

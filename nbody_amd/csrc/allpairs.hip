@@ -1,0 +1,414 @@
+// All-pairs gravity on gfx950: LDS-tiled force kernel, finalize/integrate kernels, energy.
+//
+// Replaces the compute pass of src/nbody_gpu.rs:418-451 running src/nbody.wgsl:10-139, and the
+// rayon loop of src/nbody_cpu.rs:324-349.  The reference streams every source from global memory
+// in every thread; here a workgroup stages 512-source tiles {x,y,z,m} in LDS with coalesced
+// 16-byte loads (double buffered, one barrier per tile), every lane keeps IPT targets in
+// registers, and the LDS read of a source is a wave-wide broadcast.
+//
+// FP32 VALU bound.  Per PLUMMER interaction the inner loop issues 12 full-rate VALU instructions
+// (3 sub, 3 fma, 3 mul, 3 fma) and one quarter-rate v_rsq_f32.
+#include "ctx.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+
+namespace {
+
+constexpr int BLOCK = 256;  // 4 wavefronts
+constexpr int TJ = 512;     // sources per LDS tile (8 KiB), two tiles per workgroup
+constexpr int JL = TJ / BLOCK;
+
+struct Tgt {
+    float x, y, z;
+    float vx, vy, vz, vn;  // WGSL_BIAS only: target velocity and its norm
+    int idx;               // global body index (CPU_R6 self test)
+};
+
+// acos(q) for q in [-1,1]: sqrt(1-|q|) * P7(|q|), reflected for q < 0 (Abramowitz & Stegun
+// 4.4.46, |error| <= 2e-8 before f32 rounding).
+__device__ __forceinline__ float fast_acos(float q) {
+    float a = fminf(fabsf(q), 1.0f);
+    float p = -0.0012624911f;
+    p = fmaf(p, a, 0.0066700901f);
+    p = fmaf(p, a, -0.0170881256f);
+    p = fmaf(p, a, 0.0308918810f);
+    p = fmaf(p, a, -0.0501743046f);
+    p = fmaf(p, a, 0.0889789874f);
+    p = fmaf(p, a, -0.2145988016f);
+    p = fmaf(p, a, 1.5707963050f);
+    float r = __builtin_amdgcn_sqrtf(1.0f - a) * p;
+    return q < 0.0f ? 3.14159265358979f - r : r;
+}
+
+// One source term added to (ax,ay,az).  G is applied once per target afterwards.
+// SELF: compare the source's global index with the target's (CPU_R6 skips n2 == n,
+// src/nbody_cpu.rs:335).
+template <int LAW, bool SELF>
+__device__ __forceinline__ void interact(const Tgt& t, const float4 s, int jglob, float eps2, float& ax, float& ay,
+                                         float& az) {
+    float dx = s.x - t.x, dy = s.y - t.y, dz = s.z - t.z;
+    float sc;
+    if (LAW == NBODY_LAW_CPU_R6) {
+        // src/nbody_cpu.rs:337-340: m*d / (d.d)^3
+        float r2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+        float r6 = r2 * r2 * r2;
+        sc = s.w * __builtin_amdgcn_rcpf(r6);
+        if (SELF) sc = (jglob == t.idx) ? 0.0f : sc;
+    } else if (LAW == NBODY_LAW_PLUMMER) {
+        // src/nbody.wgsl:56-65 without :74-79
+        float r2 = fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, eps2)));
+        float rinv = __builtin_amdgcn_rsqf(r2);
+        sc = (s.w * rinv) * (rinv * rinv);
+    } else {
+        // src/nbody.wgsl:56-79
+        float r2u = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+        float dist = __builtin_amdgcn_sqrtf(r2u);
+        float rinv = __builtin_amdgcn_rsqf(r2u + eps2);
+        sc = (s.w * rinv) * (rinv * rinv);
+        float vd = fmaf(t.vx, dx, fmaf(t.vy, dy, t.vz * dz));
+        float q = vd * __builtin_amdgcn_rcpf(fmaf(dist, t.vn, 1.0f));
+        float b = fast_acos(q);
+        // pow(b, 0.15) = exp2(0.15*log2(b)); b == 0 gives exp2(-inf) = 0
+        sc *= __builtin_amdgcn_exp2f(0.15f * __builtin_amdgcn_logf(b));
+    }
+    ax = fmaf(sc, dx, ax);
+    ay = fmaf(sc, dy, ay);
+    az = fmaf(sc, dz, az);
+}
+
+// grid.x: target blocks of BLOCK*IPT bodies; grid.y: source slices of j_chunk bodies.
+// acc_part[slice][i - i_begin] receives the un-scaled (no G) partial sum of the slice.
+template <int LAW, int IPT>
+__global__ __launch_bounds__(BLOCK) void k_allpairs(const float4* __restrict__ posm, const float4* __restrict__ vel,
+                                                     float4* __restrict__ acc_part, int n, int i_begin, int i_count,
+                                                     int j_chunk, float eps2) {
+    __shared__ float4 tile[2][TJ];
+    const int tid = threadIdx.x;
+    const int ib = i_begin + blockIdx.x * (BLOCK * IPT);
+    const int i_end = i_begin + i_count;
+
+    Tgt t[IPT];
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        int ig = ib + k * BLOCK + tid;
+        int ic = min(ig, i_end - 1);
+        float4 p = posm[ic];
+        t[k].x = p.x;
+        t[k].y = p.y;
+        t[k].z = p.z;
+        t[k].idx = ig;
+        if (LAW == NBODY_LAW_WGSL_BIAS) {
+            float4 v = vel[ic];
+            t[k].vx = v.x;
+            t[k].vy = v.y;
+            t[k].vz = v.z;
+            // distance(vec3(0), vel), src/nbody.wgsl:75
+            t[k].vn = sqrtf(fmaf(v.x, v.x, fmaf(v.y, v.y, v.z * v.z)));
+        }
+    }
+
+    const int j0 = blockIdx.y * j_chunk;
+    const int j1 = min(n, j0 + j_chunk);
+    const int ntiles = (j1 - j0 + TJ - 1) / TJ;
+
+    // running sum + Kahan compensation per target; a tile's terms are summed separately first
+    float sx[IPT], sy[IPT], sz[IPT], cx[IPT], cy[IPT], cz[IPT];
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) sx[k] = sy[k] = sz[k] = cx[k] = cy[k] = cz[k] = 0.0f;
+
+    float4 pre[JL];
+#pragma unroll
+    for (int l = 0; l < JL; ++l) pre[l] = posm[min(j0 + l * BLOCK + tid, j1 - 1)];
+#pragma unroll
+    for (int l = 0; l < JL; ++l) tile[0][l * BLOCK + tid] = pre[l];
+    __syncthreads();
+
+    int buf = 0;
+    for (int tl = 0; tl < ntiles; ++tl) {
+        const int jb = j0 + tl * TJ;
+        // prefetch the next tile into registers (index clamped: the last trip re-reads valid data)
+#pragma unroll
+        for (int l = 0; l < JL; ++l) pre[l] = posm[min(jb + TJ + l * BLOCK + tid, j1 - 1)];
+        const int cnt = min(TJ, j1 - jb);
+        float ax[IPT], ay[IPT], az[IPT];
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) ax[k] = ay[k] = az[k] = 0.0f;
+
+        const bool overlap = (LAW == NBODY_LAW_CPU_R6) && (jb < ib + BLOCK * IPT) && (jb + TJ > ib);
+        if (cnt == TJ && !overlap) {
+#pragma unroll 8
+            for (int jj = 0; jj < TJ; ++jj) {
+                const float4 s = tile[buf][jj];
+#pragma unroll
+                for (int k = 0; k < IPT; ++k) interact<LAW, false>(t[k], s, 0, eps2, ax[k], ay[k], az[k]);
+            }
+        } else {
+            for (int jj = 0; jj < cnt; ++jj) {
+                const float4 s = tile[buf][jj];
+#pragma unroll
+                for (int k = 0; k < IPT; ++k) interact<LAW, true>(t[k], s, jb + jj, eps2, ax[k], ay[k], az[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) {
+            float y, u;
+            y = ax[k] - cx[k]; u = sx[k] + y; cx[k] = (u - sx[k]) - y; sx[k] = u;
+            y = ay[k] - cy[k]; u = sy[k] + y; cy[k] = (u - sy[k]) - y; sy[k] = u;
+            y = az[k] - cz[k]; u = sz[k] + y; cz[k] = (u - sz[k]) - y; sz[k] = u;
+        }
+#pragma unroll
+        for (int l = 0; l < JL; ++l) tile[buf ^ 1][l * BLOCK + tid] = pre[l];
+        __syncthreads();
+        buf ^= 1;
+    }
+
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        int ig = ib + k * BLOCK + tid;
+        if (ig < i_end) acc_part[(size_t)blockIdx.y * i_count + (ig - i_begin)] = make_float4(sx[k], sy[k], sz[k], 0.0f);
+    }
+}
+
+// acc_out[i] = G * sum over slices (f64), for i in [i_begin, i_begin + i_count)
+__global__ void k_finalize(const float4* __restrict__ acc_part, int slices, int i_begin, int i_count, float G,
+                           float4* __restrict__ acc_out) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= i_count) return;
+    double x = 0, y = 0, z = 0;
+    for (int s = 0; s < slices; ++s) {
+        float4 p = acc_part[(size_t)s * i_count + r];
+        x += p.x;
+        y += p.y;
+        z += p.z;
+    }
+    acc_out[i_begin + r] = make_float4(G * (float)x, G * (float)y, G * (float)z, 0.0f);
+}
+
+// src/nbody.wgsl:132-138 / src/nbodybh.wgsl:163-169, evaluated in the reference's operation
+// order with no contraction so that equal accelerations give bit-equal states.
+__global__ void k_integrate_verlet(const float4* __restrict__ posm_in, const float4* __restrict__ vel_in,
+                                   const float4* __restrict__ acc_in, const float4* __restrict__ acc_new,
+                                   float4* __restrict__ posm_out, float4* __restrict__ vel_out,
+                                   float4* __restrict__ acc_out, int i_begin, int i_count, float dt, float dt2,
+                                   float clamp_world) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= i_count) return;
+    int i = i_begin + r;
+    float4 p = posm_in[i], v = vel_in[i], a0 = acc_in[i], a1 = acc_new[i];
+    float px = __fadd_rn(p.x, __fadd_rn(__fmul_rn(v.x, dt), __fmul_rn(__fmul_rn(0.5f, a0.x), dt2)));
+    float py = __fadd_rn(p.y, __fadd_rn(__fmul_rn(v.y, dt), __fmul_rn(__fmul_rn(0.5f, a0.y), dt2)));
+    float pz = __fadd_rn(p.z, __fadd_rn(__fmul_rn(v.z, dt), __fmul_rn(__fmul_rn(0.5f, a0.z), dt2)));
+    float vx = __fadd_rn(v.x, __fmul_rn(__fmul_rn(0.5f, __fadd_rn(a0.x, a1.x)), dt));
+    float vy = __fadd_rn(v.y, __fmul_rn(__fmul_rn(0.5f, __fadd_rn(a0.y, a1.y)), dt));
+    float vz = __fadd_rn(v.z, __fmul_rn(__fmul_rn(0.5f, __fadd_rn(a0.z, a1.z)), dt));
+    if (clamp_world > 0.0f) {
+        px = fminf(fmaxf(px, 0.0f), clamp_world);
+        py = fminf(fmaxf(py, 0.0f), clamp_world);
+        pz = fminf(fmaxf(pz, 0.0f), clamp_world);
+    }
+    posm_out[i] = make_float4(px, py, pz, p.w);
+    vel_out[i] = make_float4(vx, vy, vz, 0.0f);
+    acc_out[i] = make_float4(a1.x, a1.y, a1.z, 0.0f);
+}
+
+// src/nbody_cpu.rs:345-348: the OTHER buffer set is advanced in place.
+__global__ void k_integrate_cpu_xbuf(const float4* __restrict__ acc_new, float4* __restrict__ posm_alt,
+                                     float4* __restrict__ vel_alt, float4* __restrict__ acc_alt, int i_begin,
+                                     int i_count) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= i_count) return;
+    int i = i_begin + r;
+    float4 a = acc_new[i], v = vel_alt[i], p = posm_alt[i];
+    acc_alt[i] = make_float4(a.x, a.y, a.z, 0.0f);
+    v.x = __fadd_rn(v.x, a.x);
+    v.y = __fadd_rn(v.y, a.y);
+    v.z = __fadd_rn(v.z, a.z);
+    vel_alt[i] = make_float4(v.x, v.y, v.z, 0.0f);
+    posm_alt[i] = make_float4(__fadd_rn(p.x, v.x), __fadd_rn(p.y, v.y), __fadd_rn(p.z, v.z), p.w);
+}
+
+// K = sum 0.5 m v^2 ; U = -G/2 sum_i sum_{j != i} m_i m_j / sqrt(r^2 + eps2), in f64.
+__global__ void k_energy(const float4* __restrict__ posm, const float4* __restrict__ vel, int n, double eps2,
+                         double* __restrict__ out) {
+    __shared__ double sk[256], su[256];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double k = 0, u = 0;
+    if (i < n) {
+        float4 p = posm[i], v = vel[i];
+        k = 0.5 * (double)p.w * ((double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z);
+        for (int j = 0; j < n; ++j) {
+            if (j == i) continue;
+            float4 q = posm[j];
+            double dx = (double)q.x - p.x, dy = (double)q.y - p.y, dz = (double)q.z - p.z;
+            u += (double)q.w / sqrt(dx * dx + dy * dy + dz * dz + eps2);
+        }
+        u *= (double)p.w;
+    }
+    sk[threadIdx.x] = k;
+    su[threadIdx.x] = u;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            sk[threadIdx.x] += sk[threadIdx.x + s];
+            su[threadIdx.x] += su[threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        atomicAdd(&out[0], sk[0]);
+        atomicAdd(&out[1], su[0]);
+    }
+}
+
+int env_int(const char* name, int dflt) {
+    const char* s = getenv(name);
+    return s ? atoi(s) : dflt;
+}
+
+template <int LAW, int IPT>
+void launch_ap(nbody_ctx* ctx, const float4* posm, const float4* vel, int slices, int j_chunk) {
+    dim3 grid((unsigned)((ctx->i_count + BLOCK * IPT - 1) / (BLOCK * IPT)), (unsigned)slices);
+    hipLaunchKernelGGL((k_allpairs<LAW, IPT>), grid, dim3(BLOCK), 0, ctx->stream, posm, vel, ctx->acc_part, (int)ctx->n,
+                       (int)ctx->i_begin, (int)ctx->i_count, j_chunk, ctx->cfg.eps2);
+}
+
+template <int LAW>
+void launch_ap_ipt(nbody_ctx* ctx, const float4* posm, const float4* vel, int ipt, int slices, int j_chunk) {
+    switch (ipt) {
+        case 1: launch_ap<LAW, 1>(ctx, posm, vel, slices, j_chunk); break;
+        case 2: launch_ap<LAW, 2>(ctx, posm, vel, slices, j_chunk); break;
+        case 8: launch_ap<LAW, 8>(ctx, posm, vel, slices, j_chunk); break;
+        default: launch_ap<LAW, 4>(ctx, posm, vel, slices, j_chunk); break;
+    }
+}
+
+}  // namespace
+
+void nb_time_begin(nbody_ctx* ctx, int which) {
+    if (!ctx->timing) return;
+    auto& v = which ? ctx->ev_bh : ctx->ev_ap;
+    if (v.size() >= 2048) nb_time_collect(ctx, which);
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return;
+    v.push_back(e0);
+    v.push_back(e1);
+    hipEventRecord(e0, ctx->stream);
+}
+void nb_time_end(nbody_ctx* ctx, int which) {
+    if (!ctx->timing) return;
+    auto& v = which ? ctx->ev_bh : ctx->ev_ap;
+    if (v.size() >= 2) hipEventRecord(v.back(), ctx->stream);
+}
+int nb_time_collect(nbody_ctx* ctx, int which) {
+    auto& v = which ? ctx->ev_bh : ctx->ev_ap;
+    if (v.empty()) return NBODY_OK;
+    NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t k = 0; k + 1 < v.size(); k += 2) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, v[k], v[k + 1]) == hipSuccess) {
+            ctx->time_acc_ms[which] += ms;
+            ctx->time_launches[which] += 1;
+        }
+        hipEventDestroy(v[k]);
+        hipEventDestroy(v[k + 1]);
+    }
+    v.clear();
+    return NBODY_OK;
+}
+
+// Forces on this context's targets from all n sources in posm_in; acc_out[i] for i in the range.
+int nb_allpairs_forces(nbody_ctx* ctx, const float4* posm_in, const float4* vel_in, float4* acc_out) {
+    const int law = ctx->cfg.law;
+    int ipt = env_int("NBODY_AP_IPT", 0);
+    if (ipt != 1 && ipt != 2 && ipt != 4 && ipt != 8) {
+        // enough target blocks to fill the chip, else fewer targets per lane
+        ipt = 4;
+        while (ipt > 1 && ctx->i_count / (uint64_t)(BLOCK * ipt) < (uint64_t)ctx->num_cus) ipt >>= 1;
+    }
+    const uint64_t tblocks = (ctx->i_count + BLOCK * ipt - 1) / (BLOCK * ipt);
+    int slices = env_int("NBODY_AP_SLICES", 0);
+    const int max_slices = (int)std::max<uint64_t>(1, (ctx->n + TJ - 1) / TJ);
+    if (slices <= 0) {
+        // aim at >= 8 workgroups per CU in total
+        uint64_t want = (uint64_t)ctx->num_cus * 8;
+        slices = (int)std::min<uint64_t>(64, (want + tblocks - 1) / tblocks);
+    }
+    slices = std::max(1, std::min(slices, max_slices));
+    // slice length: a whole number of tiles
+    uint64_t tiles = (ctx->n + TJ - 1) / TJ;
+    uint64_t tiles_per_slice = (tiles + slices - 1) / slices;
+    int j_chunk = (int)(tiles_per_slice * TJ);
+    slices = (int)((ctx->n + j_chunk - 1) / j_chunk);
+
+    if ((uint64_t)slices > ctx->acc_part_slices) {
+        if (ctx->acc_part) NB_HIP(ctx, hipFree(ctx->acc_part));
+        ctx->acc_part = nullptr;
+        NB_HIP(ctx, hipMalloc(&ctx->acc_part, (size_t)slices * ctx->i_count * sizeof(float4)));
+        ctx->acc_part_slices = slices;
+    }
+
+    nb_time_begin(ctx, 0);
+    switch (law) {
+        case NBODY_LAW_CPU_R6: launch_ap_ipt<NBODY_LAW_CPU_R6>(ctx, posm_in, vel_in, ipt, slices, j_chunk); break;
+        case NBODY_LAW_WGSL_BIAS: launch_ap_ipt<NBODY_LAW_WGSL_BIAS>(ctx, posm_in, vel_in, ipt, slices, j_chunk); break;
+        default: launch_ap_ipt<NBODY_LAW_PLUMMER>(ctx, posm_in, vel_in, ipt, slices, j_chunk); break;
+    }
+    nb_time_end(ctx, 0);
+    NB_HIP(ctx, hipGetLastError());
+    const float G = (law == NBODY_LAW_CPU_R6) ? 0.0066743f : ctx->cfg.G;
+    unsigned fb = (unsigned)((ctx->i_count + 255) / 256);
+    hipLaunchKernelGGL(k_finalize, dim3(fb), dim3(256), 0, ctx->stream, ctx->acc_part, slices, (int)ctx->i_begin,
+                       (int)ctx->i_count, G, acc_out);
+    NB_HIP(ctx, hipGetLastError());
+    ctx->counters.interactions_allpairs +=
+        (law == NBODY_LAW_CPU_R6) ? ctx->i_count * (ctx->n - 1) : ctx->i_count * ctx->n;
+    return NBODY_OK;
+}
+
+// Advance the state with the accelerations acc_new (indexed by global body) and swap the sets.
+int nb_integrate(nbody_ctx* ctx, const float4* acc_new) {
+    unsigned fb = (unsigned)((ctx->i_count + 255) / 256);
+    const int c = ctx->cur, o = ctx->cur ^ 1;
+    if (ctx->cfg.integrator == NBODY_INT_CPU_EULER_XBUF) {
+        hipLaunchKernelGGL(k_integrate_cpu_xbuf, dim3(fb), dim3(256), 0, ctx->stream, acc_new, ctx->posm[o], ctx->vel[o],
+                           ctx->acc[o], (int)ctx->i_begin, (int)ctx->i_count);
+    } else {
+        const float dt = ctx->cfg.dt;
+        const float dt2 = std::pow(dt, 2.0f);  // pow(time_step, 2.0), src/nbody.wgsl:132
+        hipLaunchKernelGGL(k_integrate_verlet, dim3(fb), dim3(256), 0, ctx->stream, ctx->posm[c], ctx->vel[c],
+                           ctx->acc[c], acc_new, ctx->posm[o], ctx->vel[o], ctx->acc[o], (int)ctx->i_begin,
+                           (int)ctx->i_count, dt, dt2, 0.0f);
+    }
+    NB_HIP(ctx, hipGetLastError());
+    ctx->cur = o;
+    return NBODY_OK;
+}
+
+int nb_integrate_clamped(nbody_ctx* ctx, const float4* acc_new) {
+    unsigned fb = (unsigned)((ctx->i_count + 255) / 256);
+    const int c = ctx->cur, o = ctx->cur ^ 1;
+    const float dt = ctx->cfg.dt;
+    const float dt2 = std::pow(dt, 2.0f);
+    hipLaunchKernelGGL(k_integrate_verlet, dim3(fb), dim3(256), 0, ctx->stream, ctx->posm[c], ctx->vel[c], ctx->acc[c],
+                       acc_new, ctx->posm[o], ctx->vel[o], ctx->acc[o], (int)ctx->i_begin, (int)ctx->i_count, dt, dt2,
+                       ctx->cfg.world);
+    NB_HIP(ctx, hipGetLastError());
+    ctx->cur = o;
+    return NBODY_OK;
+}
+
+int nb_energy(nbody_ctx* ctx, double* kinetic, double* potential) {
+    if (!ctx->energy_dev) NB_HIP(ctx, hipMalloc(&ctx->energy_dev, 2 * sizeof(double)));
+    NB_HIP(ctx, hipMemsetAsync(ctx->energy_dev, 0, 2 * sizeof(double), ctx->stream));
+    unsigned fb = (unsigned)((ctx->n + 255) / 256);
+    hipLaunchKernelGGL(k_energy, dim3(fb), dim3(256), 0, ctx->stream, ctx->posm[ctx->cur], ctx->vel[ctx->cur],
+                       (int)ctx->n, (double)ctx->cfg.eps2, ctx->energy_dev);
+    NB_HIP(ctx, hipGetLastError());
+    double h[2];
+    NB_HIP(ctx, hipMemcpyAsync(h, ctx->energy_dev, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (kinetic) *kinetic = h[0];
+    if (potential) *potential = -0.5 * (double)ctx->cfg.G * h[1];
+    return NBODY_OK;
+}

@@ -1,0 +1,413 @@
+// C ABI of libnbody_hip.so (declared in include/nbody_hip.h): context, buffers, step drivers.
+#include "ctx.h"
+#include <cstring>
+#include <cmath>
+#include <new>
+
+thread_local std::string g_nbody_create_error;
+
+int nb_integrate_clamped(nbody_ctx* ctx, const float4* acc_new);
+
+namespace {
+
+__global__ void k_pack_posm(const float4* __restrict__ pos16, const float* __restrict__ masses, float4* __restrict__ posm,
+                            int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 p = pos16[i];
+    posm[i] = make_float4(p.x, p.y, p.z, masses[i]);
+}
+
+__global__ void k_strip_pad(const float4* __restrict__ posm, float4* __restrict__ pos16, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 p = posm[i];
+    pos16[i] = make_float4(p.x, p.y, p.z, 0.0f);
+}
+
+int set_device(nbody_ctx* ctx) {
+    NB_HIP(ctx, hipSetDevice(ctx->device));
+    return NBODY_OK;
+}
+
+int upload_set(nbody_ctx* ctx, int s, const float* masses, const float* pos16, const float* vel16, const float* acc16,
+               bool need_pos) {
+    const size_t b16 = ctx->n * sizeof(float4);
+    if (pos16) {
+        // stage through acc_tmp: pos16 -> device, then pack the mass into the pad lane
+        NB_HIP(ctx, hipMemcpyAsync(ctx->acc_tmp, pos16, b16, hipMemcpyHostToDevice, ctx->stream));
+        if (masses) NB_HIP(ctx, hipMemcpyAsync(ctx->masses, masses, ctx->n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        unsigned nb = (unsigned)((ctx->n + 255) / 256);
+        hipLaunchKernelGGL(k_pack_posm, dim3(nb), dim3(256), 0, ctx->stream, ctx->acc_tmp, ctx->masses, ctx->posm[s],
+                           (int)ctx->n);
+        NB_HIP(ctx, hipGetLastError());
+    } else if (need_pos) {
+        return nb_fail(ctx, NBODY_ERR_INVALID, "positions are required");
+    } else {
+        // zero positions, masses kept in the pad lane
+        NB_HIP(ctx, hipMemsetAsync(ctx->acc_tmp, 0, b16, ctx->stream));
+        unsigned nb = (unsigned)((ctx->n + 255) / 256);
+        hipLaunchKernelGGL(k_pack_posm, dim3(nb), dim3(256), 0, ctx->stream, ctx->acc_tmp, ctx->masses, ctx->posm[s],
+                           (int)ctx->n);
+        NB_HIP(ctx, hipGetLastError());
+    }
+    if (vel16) NB_HIP(ctx, hipMemcpyAsync(ctx->vel[s], vel16, b16, hipMemcpyHostToDevice, ctx->stream));
+    else NB_HIP(ctx, hipMemsetAsync(ctx->vel[s], 0, b16, ctx->stream));
+    if (acc16) NB_HIP(ctx, hipMemcpyAsync(ctx->acc[s], acc16, b16, hipMemcpyHostToDevice, ctx->stream));
+    else NB_HIP(ctx, hipMemsetAsync(ctx->acc[s], 0, b16, ctx->stream));
+    // the host buffers may be pageable: make sure the copies have consumed them
+    NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NBODY_OK;
+}
+
+int download_set(nbody_ctx* ctx, int s, float* pos16, float* vel16, float* acc16) {
+    const size_t b16 = ctx->n * sizeof(float4);
+    if (pos16) {
+        unsigned nb = (unsigned)((ctx->n + 255) / 256);
+        hipLaunchKernelGGL(k_strip_pad, dim3(nb), dim3(256), 0, ctx->stream, ctx->posm[s], ctx->acc_tmp, (int)ctx->n);
+        NB_HIP(ctx, hipGetLastError());
+        NB_HIP(ctx, hipMemcpyAsync(pos16, ctx->acc_tmp, b16, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (vel16) NB_HIP(ctx, hipMemcpyAsync(vel16, ctx->vel[s], b16, hipMemcpyDeviceToHost, ctx->stream));
+    if (acc16) NB_HIP(ctx, hipMemcpyAsync(acc16, ctx->acc[s], b16, hipMemcpyDeviceToHost, ctx->stream));
+    NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NBODY_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* nbody_version(void) { return "nbody_hip 0.1 (gfx950)"; }
+
+const char* nbody_last_error(const nbody_ctx* ctx) { return ctx ? ctx->err.c_str() : g_nbody_create_error.c_str(); }
+
+void nbody_config_default(nbody_config* cfg) {
+    if (!cfg) return;
+    std::memset(cfg, 0, sizeof *cfg);
+    cfg->n_bodies = 250;  // N_BODIES, src/nbody_gpu.rs:14
+    cfg->law = NBODY_LAW_WGSL_BIAS;
+    cfg->integrator = NBODY_INT_WGSL_VERLET;
+    cfg->G = 0.0066743f;
+    cfg->dt = 0.1f;
+    cfg->eps2 = 1.0f;
+    cfg->theta = 0.5f;
+    cfg->world = 250.0f;
+    cfg->max_depth = 16;
+    cfg->leaflist_mode = 0;
+    cfg->shard_begin = 0;
+    cfg->shard_count = 0;
+    cfg->device = -1;
+    cfg->stream = nullptr;
+}
+
+int nbody_create(nbody_ctx** out, const nbody_config* cfg) {
+    if (!out || !cfg) {
+        g_nbody_create_error = "nbody_create: null argument";
+        return NBODY_ERR_INVALID;
+    }
+    *out = nullptr;
+    if (cfg->n_bodies == 0 || cfg->n_bodies > (1ull << 30)) {
+        g_nbody_create_error = "nbody_create: n_bodies must be in [1, 2^30]";
+        return NBODY_ERR_INVALID;
+    }
+    if (cfg->law < 0 || cfg->law > 2 || cfg->integrator < 0 || cfg->integrator > 1) {
+        g_nbody_create_error = "nbody_create: unknown law or integrator";
+        return NBODY_ERR_INVALID;
+    }
+    if (cfg->max_depth < 1 || cfg->max_depth > 16) {
+        g_nbody_create_error = "nbody_create: max_depth must be in [1,16]";
+        return NBODY_ERR_INVALID;
+    }
+    uint64_t sc = cfg->shard_count ? cfg->shard_count : cfg->n_bodies - cfg->shard_begin;
+    if (cfg->shard_begin >= cfg->n_bodies || cfg->shard_begin + sc > cfg->n_bodies) {
+        g_nbody_create_error = "nbody_create: shard range outside [0, n_bodies)";
+        return NBODY_ERR_INVALID;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        g_nbody_create_error = "nbody_create: no HIP device";
+        return NBODY_ERR_NO_DEVICE;
+    }
+    nbody_ctx* ctx = new (std::nothrow) nbody_ctx;
+    if (!ctx) {
+        g_nbody_create_error = "nbody_create: out of host memory";
+        return NBODY_ERR_NOMEM;
+    }
+    ctx->cfg = *cfg;
+    ctx->n = cfg->n_bodies;
+    ctx->i_begin = cfg->shard_begin;
+    ctx->i_count = sc;
+    int dev = cfg->device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = 0;
+    ctx->device = dev;
+    auto fail = [&](int code, const std::string& msg) {
+        g_nbody_create_error = msg;
+        nbody_destroy(ctx);
+        return code;
+    };
+    if (dev >= ndev || hipSetDevice(dev) != hipSuccess) return fail(NBODY_ERR_NO_DEVICE, "nbody_create: bad device ordinal");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail(NBODY_ERR_HIP, "hipGetDeviceProperties failed");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(NBODY_ERR_NO_DEVICE, std::string("nbody_create: device is ") + prop.gcnArchName + ", this library is built for gfx950");
+    ctx->num_cus = prop.multiProcessorCount;
+    if (cfg->stream) {
+        ctx->stream = (hipStream_t)cfg->stream;
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess)
+            return fail(NBODY_ERR_HIP, "hipStreamCreate failed");
+        ctx->own_stream = true;
+    }
+    const size_t b16 = ctx->n * sizeof(float4);
+    hipError_t e = hipSuccess;
+    for (int s = 0; s < 2 && e == hipSuccess; ++s) {
+        e = hipMalloc(&ctx->posm[s], b16);
+        if (e == hipSuccess) e = hipMalloc(&ctx->vel[s], b16);
+        if (e == hipSuccess) e = hipMalloc(&ctx->acc[s], b16);
+    }
+    if (e == hipSuccess) e = hipMalloc(&ctx->acc_tmp, b16);
+    if (e == hipSuccess) e = hipMalloc(&ctx->masses, ctx->n * sizeof(float));
+    if (e != hipSuccess) return fail(NBODY_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    for (int s = 0; s < 2; ++s) {
+        hipMemsetAsync(ctx->posm[s], 0, b16, ctx->stream);
+        hipMemsetAsync(ctx->vel[s], 0, b16, ctx->stream);
+        hipMemsetAsync(ctx->acc[s], 0, b16, ctx->stream);
+    }
+    hipMemsetAsync(ctx->masses, 0, ctx->n * sizeof(float), ctx->stream);
+    if (nb_tree_create(ctx) != NBODY_OK) return fail(NBODY_ERR_NOMEM, "octree workspace: " + ctx->err);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(NBODY_ERR_HIP, "stream sync failed");
+    *out = ctx;
+    return NBODY_OK;
+}
+
+void nbody_destroy(nbody_ctx* ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    nb_time_collect(ctx, 0);
+    nb_time_collect(ctx, 1);
+    nb_tree_destroy(ctx);
+    for (int s = 0; s < 2; ++s) {
+        if (ctx->posm[s]) hipFree(ctx->posm[s]);
+        if (ctx->vel[s]) hipFree(ctx->vel[s]);
+        if (ctx->acc[s]) hipFree(ctx->acc[s]);
+    }
+    if (ctx->acc_tmp) hipFree(ctx->acc_tmp);
+    if (ctx->acc_part) hipFree(ctx->acc_part);
+    if (ctx->masses) hipFree(ctx->masses);
+    if (ctx->energy_dev) hipFree(ctx->energy_dev);
+    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int nbody_upload(nbody_ctx* ctx, const float* host_masses, const float* host_pos16, const float* host_vel16,
+                 const float* host_acc16) {
+    if (!ctx) return NBODY_ERR_INVALID;
+    if (!host_masses || !host_pos16) return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_upload: masses and positions are required");
+    int r = set_device(ctx);
+    if (r) return r;
+    ctx->cur = 0;
+    r = upload_set(ctx, 0, host_masses, host_pos16, host_vel16, host_acc16, true);
+    if (r) return r;
+    // second set: zeros (src/nbody_cpu.rs:58-60), mass kept in the pad lane
+    r = upload_set(ctx, 1, nullptr, nullptr, nullptr, nullptr, false);
+    if (r) return r;
+    ctx->uploaded = true;
+    return NBODY_OK;
+}
+
+int nbody_upload_alt(nbody_ctx* ctx, const float* host_pos16, const float* host_vel16, const float* host_acc16) {
+    if (!ctx) return NBODY_ERR_INVALID;
+    if (!ctx->uploaded) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_upload_alt: call nbody_upload first");
+    int r = set_device(ctx);
+    if (r) return r;
+    return upload_set(ctx, ctx->cur ^ 1, nullptr, host_pos16, host_vel16, host_acc16, false);
+}
+
+int nbody_step_allpairs(nbody_ctx* ctx, int nsteps) {
+    if (!ctx) return NBODY_ERR_INVALID;
+    if (!ctx->uploaded) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_step_allpairs: no bodies uploaded");
+    if (nsteps < 0) return nb_fail(ctx, NBODY_ERR_INVALID, "nsteps < 0");
+    if (ctx->i_count < ctx->n && nsteps > 1)
+        return nb_fail(ctx, NBODY_ERR_INVALID, "a sharded context steps once per call: all-gather NBODY_BUF_POSM between steps");
+    int r = set_device(ctx);
+    if (r) return r;
+    for (int s = 0; s < nsteps; ++s) {
+        r = nb_allpairs_forces(ctx, ctx->posm[ctx->cur], ctx->vel[ctx->cur], ctx->acc_tmp);
+        if (r) return r;
+        r = nb_integrate(ctx, ctx->acc_tmp);
+        if (r) return r;
+        ctx->counters.steps_allpairs += 1;
+    }
+    return NBODY_OK;
+}
+
+int nbody_step_bh(nbody_ctx* ctx, int nsteps) {
+    if (!ctx) return NBODY_ERR_INVALID;
+    if (!ctx->uploaded) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_step_bh: no bodies uploaded");
+    if (nsteps < 0) return nb_fail(ctx, NBODY_ERR_INVALID, "nsteps < 0");
+    if (ctx->cfg.law == NBODY_LAW_CPU_R6)
+        return nb_fail(ctx, NBODY_ERR_INVALID, "the Barnes-Hut path uses the WGSL laws (src/nbodybh.wgsl), not CPU_R6");
+    if (ctx->i_count < ctx->n && nsteps > 1)
+        return nb_fail(ctx, NBODY_ERR_INVALID, "a sharded context steps once per call: all-gather NBODY_BUF_POSM between steps");
+    int r = set_device(ctx);
+    if (r) return r;
+    for (int s = 0; s < nsteps; ++s) {
+        r = nb_tree_build(ctx, ctx->posm[ctx->cur]);
+        if (r) return r;
+        r = nb_tree_walk(ctx, ctx->posm[ctx->cur], ctx->vel[ctx->cur], ctx->acc_tmp);
+        if (r) return r;
+        r = nb_integrate_clamped(ctx, ctx->acc_tmp);
+        if (r) return r;
+        ctx->counters.steps_bh += 1;
+    }
+    return NBODY_OK;
+}
+
+int nbody_accel_allpairs(nbody_ctx* ctx, float* host_acc16_out) {
+    if (!ctx || !host_acc16_out) return NBODY_ERR_INVALID;
+    if (!ctx->uploaded) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_accel_allpairs: no bodies uploaded");
+    int r = set_device(ctx);
+    if (r) return r;
+    r = nb_allpairs_forces(ctx, ctx->posm[ctx->cur], ctx->vel[ctx->cur], ctx->acc_tmp);
+    if (r) return r;
+    NB_HIP(ctx, hipMemcpyAsync(host_acc16_out + 4 * ctx->i_begin, ctx->acc_tmp + ctx->i_begin,
+                               ctx->i_count * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NBODY_OK;
+}
+
+int nbody_accel_bh(nbody_ctx* ctx, float* host_acc16_out) {
+    if (!ctx || !host_acc16_out) return NBODY_ERR_INVALID;
+    if (!ctx->uploaded) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_accel_bh: no bodies uploaded");
+    if (ctx->cfg.law == NBODY_LAW_CPU_R6)
+        return nb_fail(ctx, NBODY_ERR_INVALID, "the Barnes-Hut path uses the WGSL laws (src/nbodybh.wgsl), not CPU_R6");
+    int r = set_device(ctx);
+    if (r) return r;
+    r = nb_tree_walk(ctx, ctx->posm[ctx->cur], ctx->vel[ctx->cur], ctx->acc_tmp);
+    if (r) return r;
+    NB_HIP(ctx, hipMemcpyAsync(host_acc16_out + 4 * ctx->i_begin, ctx->acc_tmp + ctx->i_begin,
+                               ctx->i_count * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NBODY_OK;
+}
+
+int nbody_build_octree(nbody_ctx* ctx) {
+    if (!ctx) return NBODY_ERR_INVALID;
+    if (!ctx->uploaded) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_build_octree: no bodies uploaded");
+    int r = set_device(ctx);
+    if (r) return r;
+    return nb_tree_build(ctx, ctx->posm[ctx->cur]);
+}
+
+int nbody_download_octree(nbody_ctx* ctx, nbody_octree_node* host_nodes, uint64_t cap_nodes, uint64_t* n_nodes) {
+    if (!ctx) return NBODY_ERR_INVALID;
+    int r = set_device(ctx);
+    if (r) return r;
+    return nb_tree_download(ctx, host_nodes, cap_nodes, n_nodes);
+}
+
+int nbody_upload_octree(nbody_ctx* ctx, const nbody_octree_node* host_nodes, uint64_t n_nodes) {
+    if (!ctx || !host_nodes || n_nodes == 0) return ctx ? nb_fail(ctx, NBODY_ERR_INVALID, "nbody_upload_octree: empty tree") : NBODY_ERR_INVALID;
+    int r = set_device(ctx);
+    if (r) return r;
+    return nb_tree_upload(ctx, host_nodes, n_nodes);
+}
+
+int nbody_morton_keys(nbody_ctx* ctx, uint64_t* host_keys, uint8_t* host_leaf_depth, uint32_t* host_order) {
+    if (!ctx) return NBODY_ERR_INVALID;
+    int r = set_device(ctx);
+    if (r) return r;
+    return nb_tree_keys(ctx, host_keys, host_leaf_depth, host_order);
+}
+
+int nbody_download(nbody_ctx* ctx, float* host_pos16, float* host_vel16, float* host_acc16) {
+    if (!ctx) return NBODY_ERR_INVALID;
+    if (!ctx->uploaded) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_download: no bodies uploaded");
+    int r = set_device(ctx);
+    if (r) return r;
+    return download_set(ctx, ctx->cur, host_pos16, host_vel16, host_acc16);
+}
+
+int nbody_download_alt(nbody_ctx* ctx, float* host_pos16, float* host_vel16, float* host_acc16) {
+    if (!ctx) return NBODY_ERR_INVALID;
+    if (!ctx->uploaded) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_download_alt: no bodies uploaded");
+    int r = set_device(ctx);
+    if (r) return r;
+    return download_set(ctx, ctx->cur ^ 1, host_pos16, host_vel16, host_acc16);
+}
+
+int nbody_sync(nbody_ctx* ctx) {
+    if (!ctx) return NBODY_ERR_INVALID;
+    int r = set_device(ctx);
+    if (r) return r;
+    NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NBODY_OK;
+}
+
+int nbody_energy(nbody_ctx* ctx, double* kinetic, double* potential) {
+    if (!ctx) return NBODY_ERR_INVALID;
+    if (!ctx->uploaded) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_energy: no bodies uploaded");
+    if (ctx->i_count < ctx->n) return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_energy needs an unsharded context");
+    int r = set_device(ctx);
+    if (r) return r;
+    return nb_energy(ctx, kinetic, potential);
+}
+
+int nbody_counters(nbody_ctx* ctx, nbody_counters_t* out) {
+    if (!ctx || !out) return NBODY_ERR_INVALID;
+    int r = set_device(ctx);
+    if (r) return r;
+    NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *out = ctx->counters;
+    return NBODY_OK;
+}
+
+int nbody_counters_reset(nbody_ctx* ctx) {
+    if (!ctx) return NBODY_ERR_INVALID;
+    ctx->counters = nbody_counters_t{};
+    return NBODY_OK;
+}
+
+int nbody_set_counting(nbody_ctx* ctx, int on) {
+    if (!ctx) return NBODY_ERR_INVALID;
+    ctx->counting = on != 0;
+    return NBODY_OK;
+}
+
+int nbody_device_buffer(nbody_ctx* ctx, int which, void** dev_ptr, size_t* bytes) {
+    if (!ctx || !dev_ptr) return NBODY_ERR_INVALID;
+    size_t b16 = ctx->n * sizeof(float4);
+    switch (which) {
+        case NBODY_BUF_POSM: *dev_ptr = ctx->posm[ctx->cur]; if (bytes) *bytes = b16; return NBODY_OK;
+        case NBODY_BUF_VEL: *dev_ptr = ctx->vel[ctx->cur]; if (bytes) *bytes = b16; return NBODY_OK;
+        case NBODY_BUF_ACC: *dev_ptr = ctx->acc[ctx->cur]; if (bytes) *bytes = b16; return NBODY_OK;
+        case NBODY_BUF_OCTREE: return nb_tree_device_nodes(ctx, dev_ptr, bytes);
+        default: return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_device_buffer: unknown buffer");
+    }
+}
+
+void* nbody_stream(nbody_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int nbody_set_kernel_timing(nbody_ctx* ctx, int on) {
+    if (!ctx) return NBODY_ERR_INVALID;
+    ctx->timing = on != 0;
+    return NBODY_OK;
+}
+
+int nbody_kernel_time(nbody_ctx* ctx, int bh, double* avg_ms, uint64_t* launches) {
+    if (!ctx) return NBODY_ERR_INVALID;
+    int which = bh ? 1 : 0;
+    int r = set_device(ctx);
+    if (r) return r;
+    r = nb_time_collect(ctx, which);
+    if (r) return r;
+    if (launches) *launches = ctx->time_launches[which];
+    if (avg_ms) *avg_ms = ctx->time_launches[which] ? ctx->time_acc_ms[which] / (double)ctx->time_launches[which] : 0.0;
+    ctx->time_acc_ms[which] = 0;
+    ctx->time_launches[which] = 0;
+    return NBODY_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,87 @@
+// Internal state of an nbody_ctx and helpers shared by the translation units of libnbody_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+#include "../../include/nbody_hip.h"
+
+struct nbody_ctx {
+    nbody_config cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cus = 256;
+    std::string err;
+
+    uint64_t n = 0;        // all bodies
+    uint64_t i_begin = 0;  // this context's targets
+    uint64_t i_count = 0;
+    bool uploaded = false;
+
+    // Body state in HBM.  Two sets (the reference's bind groups A and B, src/nbody_gpu.rs:145-288);
+    // `cur` is the set the next step reads.  posm[s][i] = {x, y, z, mass_i}.
+    float4* posm[2] = {nullptr, nullptr};
+    float4* vel[2] = {nullptr, nullptr};
+    float4* acc[2] = {nullptr, nullptr};
+    float* masses = nullptr;
+    int cur = 0;
+
+    // All-pairs scratch: per source-slice partial accelerations [slices][i_count].
+    float4* acc_part = nullptr;
+    uint64_t acc_part_slices = 0;
+    float4* acc_tmp = nullptr;  // [n] forces-only output / finalize target
+
+    // Octree state (octree.hip)
+    struct Octree* tree = nullptr;
+
+    // energy scratch
+    double* energy_dev = nullptr;
+
+    nbody_counters_t counters{};
+    bool counting = false;
+
+    // kernel timing (HIP events on `stream`)
+    bool timing = false;
+    std::vector<hipEvent_t> ev_pool;  // pairs
+    size_t ev_used[2] = {0, 0};       // [0]=all-pairs, [1]=bh : number of recorded pairs
+    std::vector<hipEvent_t> ev_ap, ev_bh;
+    double time_acc_ms[2] = {0, 0};
+    uint64_t time_launches[2] = {0, 0};
+};
+
+extern thread_local std::string g_nbody_create_error;
+
+#define NB_HIP(ctx, call)                                                                          \
+    do {                                                                                           \
+        hipError_t _e = (call);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(_e);                        \
+            return NBODY_ERR_HIP;                                                                  \
+        }                                                                                          \
+    } while (0)
+
+static inline int nb_fail(nbody_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+// all-pairs (allpairs.hip)
+int nb_allpairs_forces(nbody_ctx* ctx, const float4* posm_in, const float4* vel_in, float4* acc_out);
+int nb_integrate(nbody_ctx* ctx, const float4* acc_new);
+int nb_integrate_clamped(nbody_ctx* ctx, const float4* acc_new);
+int nb_energy(nbody_ctx* ctx, double* kinetic, double* potential);
+void nb_time_begin(nbody_ctx* ctx, int which);
+void nb_time_end(nbody_ctx* ctx, int which);
+int nb_time_collect(nbody_ctx* ctx, int which);
+
+// octree (octree.hip)
+int nb_tree_create(nbody_ctx* ctx);
+void nb_tree_destroy(nbody_ctx* ctx);
+int nb_tree_build(nbody_ctx* ctx, const float4* posm_in);
+int nb_tree_walk(nbody_ctx* ctx, const float4* posm_in, const float4* vel_in, float4* acc_out);
+int nb_tree_download(nbody_ctx* ctx, nbody_octree_node* host_nodes, uint64_t cap, uint64_t* n_nodes);
+int nb_tree_upload(nbody_ctx* ctx, const nbody_octree_node* host_nodes, uint64_t n_nodes);
+int nb_tree_keys(nbody_ctx* ctx, uint64_t* keys, uint8_t* depth, uint32_t* order);
+int nb_tree_device_nodes(nbody_ctx* ctx, void** ptr, size_t* bytes);

@@ -1,0 +1,208 @@
+"""Host-side mirror of the reference's three binaries' step blocks, over the C ABI.
+
+`NBodySim` owns one nbody_ctx.  Method names follow the reference's structure:
+  step_allpairs  <-> Event::MainEventsCleared of src/nbody_gpu.rs:418-451 / src/nbody_cpu.rs:319-360
+  step_bh        <-> Event::MainEventsCleared of src/nbody_gpu_bh.rs:445-527
+  build_octree   <-> OctreeNode::new_tree, src/octree_maxdepth.rs:26
+Arrays are numpy float32 with the reference's 16-byte vec3 stride: shape (N, 4).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import NBodyConfig, NBodyCounters
+
+LAW_CPU_R6, LAW_WGSL_BIAS, LAW_PLUMMER = 0, 1, 2
+INT_CPU_EULER_XBUF, INT_WGSL_VERLET = 0, 1
+BUF_POSM, BUF_VEL, BUF_ACC, BUF_OCTREE = 0, 1, 2, 3
+NODE_DUMMY, NODE_LEAFBODY, NODE_LEAFLIST, NODE_INTERIOR = 0, 1, 2, 3
+
+# the 96-byte node of src/nbodybh.wgsl:1-9 as a numpy record
+NODE_DTYPE = np.dtype({
+    "names": ["com", "pos_min", "pos_max", "range", "total_mass", "child", "node_type", "depth"],
+    "formats": [(np.float32, 3), (np.float32, 3), (np.float32, 3), np.float32, np.float32, (np.uint32, 8), np.uint32,
+                np.uint32],
+    "offsets": [0, 16, 32, 44, 48, 52, 84, 88],
+    "itemsize": 96,
+})
+
+
+class NBodyError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"nbody_hip error {code}: {msg}")
+        self.code = code
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32x4(a, n, name):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.shape != (n, 4):
+        raise ValueError(f"{name} must have shape ({n}, 4), got {a.shape}")
+    return a
+
+
+def default_config(n_bodies, **kw):
+    lib = _lib.load()
+    cfg = NBodyConfig()
+    lib.nbody_config_default(C.byref(cfg))
+    cfg.n_bodies = n_bodies
+    for k, v in kw.items():
+        if not hasattr(cfg, k):
+            raise TypeError(f"unknown config field {k}")
+        setattr(cfg, k, v)
+    return cfg
+
+
+def gen_refcube(n, seed=42, world=250.0, first=0):
+    """Masses (n,) and positions (n,4) following src/nbody_gpu.rs:61-81 with a seeded stream."""
+    lib = _lib.load()
+    m = np.empty(n, np.float32)
+    p = np.empty((n, 4), np.float32)
+    rc = lib.nbody_gen_refcube(seed, first, n, world, _ptr(m), _ptr(p))
+    if rc:
+        raise NBodyError(rc, "nbody_gen_refcube")
+    return m, p
+
+
+def gen_plummer(n, seed=42, world=250.0, a=12.5, rmax=100.0, total_mass=4515.625, G=0.0066743, equilibrium=False,
+                first=0, n_total=None):
+    lib = _lib.load()
+    m = np.empty(n, np.float32)
+    p = np.empty((n, 4), np.float32)
+    v = np.empty((n, 4), np.float32)
+    rc = lib.nbody_gen_plummer(seed, first, n, n_total or n, world, a, rmax, total_mass, G, int(equilibrium), _ptr(m),
+                               _ptr(p), _ptr(v))
+    if rc:
+        raise NBodyError(rc, "nbody_gen_plummer")
+    return m, p, v
+
+
+class NBodySim:
+    def __init__(self, n_bodies, **cfg):
+        self.lib = _lib.load()
+        self.cfg = default_config(n_bodies, **cfg)
+        self.n = n_bodies
+        h = C.c_void_p()
+        rc = self.lib.nbody_create(C.byref(h), C.byref(self.cfg))
+        if rc:
+            raise NBodyError(rc, self.lib.nbody_last_error(None).decode())
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.nbody_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _ck(self, rc):
+        if rc:
+            raise NBodyError(rc, self.lib.nbody_last_error(self.h).decode())
+
+    # -- buffers -------------------------------------------------------------------------------
+    def upload(self, masses, pos16, vel16=None, acc16=None):
+        m = np.ascontiguousarray(masses, dtype=np.float32)
+        if m.shape != (self.n,):
+            raise ValueError("masses must have shape (n,)")
+        p, v, a = (_f32x4(x, self.n, s) for x, s in ((pos16, "pos16"), (vel16, "vel16"), (acc16, "acc16")))
+        self._ck(self.lib.nbody_upload(self.h, _ptr(m), _ptr(p), _ptr(v), _ptr(a)))
+
+    def upload_alt(self, pos16=None, vel16=None, acc16=None):
+        p, v, a = (_f32x4(x, self.n, s) for x, s in ((pos16, "pos16"), (vel16, "vel16"), (acc16, "acc16")))
+        self._ck(self.lib.nbody_upload_alt(self.h, _ptr(p), _ptr(v), _ptr(a)))
+
+    def download(self, alt=False):
+        p, v, a = (np.empty((self.n, 4), np.float32) for _ in range(3))
+        fn = self.lib.nbody_download_alt if alt else self.lib.nbody_download
+        self._ck(fn(self.h, _ptr(p), _ptr(v), _ptr(a)))
+        return p, v, a
+
+    # -- steps ---------------------------------------------------------------------------------
+    def step_allpairs(self, nsteps=1):
+        self._ck(self.lib.nbody_step_allpairs(self.h, nsteps))
+
+    def step_bh(self, nsteps=1):
+        self._ck(self.lib.nbody_step_bh(self.h, nsteps))
+
+    def accel_allpairs(self):
+        a = np.zeros((self.n, 4), np.float32)
+        self._ck(self.lib.nbody_accel_allpairs(self.h, _ptr(a)))
+        return a
+
+    def accel_bh(self):
+        a = np.zeros((self.n, 4), np.float32)
+        self._ck(self.lib.nbody_accel_bh(self.h, _ptr(a)))
+        return a
+
+    def sync(self):
+        self._ck(self.lib.nbody_sync(self.h))
+
+    # -- octree --------------------------------------------------------------------------------
+    def build_octree(self):
+        self._ck(self.lib.nbody_build_octree(self.h))
+
+    def download_octree(self):
+        cnt = C.c_uint64()
+        self._ck(self.lib.nbody_download_octree(self.h, None, 0, C.byref(cnt)))
+        nodes = np.zeros(cnt.value, NODE_DTYPE)
+        self._ck(self.lib.nbody_download_octree(self.h, _ptr(nodes), cnt.value, C.byref(cnt)))
+        return nodes
+
+    def upload_octree(self, nodes):
+        nodes = np.ascontiguousarray(nodes)
+        if nodes.dtype.itemsize != 96:
+            raise ValueError("octree nodes must be 96-byte records")
+        self._ck(self.lib.nbody_upload_octree(self.h, _ptr(nodes), len(nodes)))
+
+    def morton_keys(self):
+        keys = np.empty(self.n, np.uint64)
+        depth = np.empty(self.n, np.uint8)
+        order = np.empty(self.n, np.uint32)
+        self._ck(self.lib.nbody_morton_keys(self.h, _ptr(keys), _ptr(depth), _ptr(order)))
+        return keys, depth, order
+
+    # -- measurement ---------------------------------------------------------------------------
+    def energy(self):
+        k, u = C.c_double(), C.c_double()
+        self._ck(self.lib.nbody_energy(self.h, C.byref(k), C.byref(u)))
+        return k.value, u.value
+
+    def counters(self):
+        c = NBodyCounters()
+        self._ck(self.lib.nbody_counters(self.h, C.byref(c)))
+        return {f: getattr(c, f) for f, _ in NBodyCounters._fields_ if f != "reserved"}
+
+    def counters_reset(self):
+        self._ck(self.lib.nbody_counters_reset(self.h))
+
+    def set_counting(self, on):
+        self._ck(self.lib.nbody_set_counting(self.h, int(on)))
+
+    def set_kernel_timing(self, on):
+        self._ck(self.lib.nbody_set_kernel_timing(self.h, int(on)))
+
+    def kernel_time(self, bh=False):
+        ms, cnt = C.c_double(), C.c_uint64()
+        self._ck(self.lib.nbody_kernel_time(self.h, int(bh), C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
+    def device_buffer(self, which):
+        p, b = C.c_void_p(), C.c_size_t()
+        self._ck(self.lib.nbody_device_buffer(self.h, which, C.byref(p), C.byref(b)))
+        return p.value, b.value
+
+    def stream(self):
+        return self.lib.nbody_stream(self.h)

@@ -1,0 +1,200 @@
+"""Known-answer tests pinning the CPU oracle to hand-derived values of the reference's formulas.
+(The reference ships no tests or fixtures for this path; these are the first pins.)"""
+import math
+
+import numpy as np
+import pytest
+
+G = np.float32(0.0066743)
+
+
+def p4(rows):
+    a = np.zeros((len(rows), 4), np.float32)
+    a[:, :3] = np.asarray(rows, np.float32)
+    return a
+
+
+def test_wgsl_self_term_is_zero_and_bias_constant(orc):
+    # src/nbody.wgsl:52-81: the loop includes i == i_id; d = 0 gives g*bias*0 = 0.
+    pos = p4([[10, 20, 30]])
+    acc = orc.accel_allpairs(orc.LAW_WGSL_BIAS, pos, p4([[0, 0, 0]]), np.array([5.0], np.float32))
+    assert np.all(acc == 0)
+    # two bodies m=1 at distance (3,0,0), v = 0: a_x = G*bias*3/(9+1)^1.5, bias = (pi/2)^0.15
+    pos = p4([[10, 20, 30], [13, 20, 30]])
+    acc = orc.accel_allpairs(orc.LAW_WGSL_BIAS, pos, p4([[0, 0, 0]] * 2), np.ones(2, np.float32))
+    bias = (math.pi / 2) ** 0.15
+    expect = float(G) * bias * 3.0 / 10.0 ** 1.5
+    assert acc[0, 0] == pytest.approx(expect, rel=2e-6)
+    assert acc[1, 0] == pytest.approx(-expect, rel=2e-6)
+    assert acc[0, 1] == 0 and acc[0, 2] == 0
+    # PLUMMER = the same without the bias
+    acc = orc.accel_allpairs(orc.LAW_PLUMMER, pos, None, np.ones(2, np.float32))
+    assert acc[0, 0] == pytest.approx(float(G) * 3.0 / 10.0 ** 1.5, rel=2e-6)
+
+
+def test_wgsl_bias_with_velocity(orc):
+    # target moving straight at the source: q = |v||d|/(|v||d|+1); bias = acos(q)^0.15
+    pos = p4([[0, 0, 0], [4, 0, 0]])
+    vel = p4([[2, 0, 0], [0, 0, 0]])
+    acc = orc.accel_allpairs(orc.LAW_WGSL_BIAS, pos, vel, np.array([1, 3], np.float32))
+    q = 8.0 / 9.0
+    expect = float(G) * 3.0 / 17.0 ** 1.5 * math.acos(q) ** 0.15 * 4.0
+    assert acc[0, 0] == pytest.approx(expect, rel=3e-6)
+    # moving away: q negative
+    vel = p4([[-2, 0, 0], [0, 0, 0]])
+    acc = orc.accel_allpairs(orc.LAW_WGSL_BIAS, pos, vel, np.array([1, 3], np.float32))
+    expect = float(G) * 3.0 / 17.0 ** 1.5 * math.acos(-q) ** 0.15 * 4.0
+    assert acc[0, 0] == pytest.approx(expect, rel=3e-6)
+
+
+def test_cpu_law_two_bodies(orc):
+    # src/nbody_cpu.rs:337-340: (G*m*d)/(dn^3) with dn = d.d: distance (2,0,0), m = 3 -> G*3*2/64
+    pos = p4([[1, 1, 1], [3, 1, 1]])
+    acc = orc.accel_allpairs(orc.LAW_CPU_R6, pos, None, np.array([7, 3], np.float32))
+    assert acc[0, 0] == np.float32(np.float32(G * np.float32(3)) * np.float32(2)) / np.float32(64)
+    assert acc[1, 0] == -(np.float32(np.float32(G * np.float32(7)) * np.float32(2)) / np.float32(64))
+    # self is skipped: a single body has zero acceleration, not NaN
+    acc = orc.accel_allpairs(orc.LAW_CPU_R6, p4([[1, 2, 3]]), None, np.ones(1, np.float32))
+    assert np.all(acc == 0)
+
+
+def test_cpu_step_cross_buffer(orc):
+    # src/nbody_cpu.rs:54-60,345-360: set 2 starts at the origin and is advanced by forces
+    # evaluated on set 1; the sets swap.
+    pos = p4([[1, 1, 1], [3, 1, 1]])
+    m = np.array([7, 3], np.float32)
+    z = np.zeros((2, 4), np.float32)
+    a = orc.accel_allpairs(orc.LAW_CPU_R6, pos, None, m)
+    p1, v1, a1, p2, v2, a2 = orc.step_cpu(m, pos, z, z, z, z, z, 1)
+    # after one step the set to read next ("1") is the old set 2: started at 0, moved by a
+    assert np.array_equal(a1, a) and np.array_equal(v1, a) and np.array_equal(p1, a)
+    assert np.array_equal(p2, pos) and np.all(v2 == 0)
+    # second step: forces from positions == a (nearly coincident bodies near the origin)
+    q1, w1, b1, q2, w2, b2 = orc.step_cpu(m, pos, z, z, z, z, z, 2)
+    a_second = orc.accel_allpairs(orc.LAW_CPU_R6, p1, None, m)
+    assert np.array_equal(b1, a_second)
+    assert np.array_equal(w1, a_second)          # vel of the original set was 0
+    assert np.array_equal(q1[:, :3], (pos + a_second)[:, :3])
+    assert np.array_equal(q2, p1)
+
+
+def test_verlet_first_step(orc):
+    # src/nbody.wgsl:132-133 with vel = acc_in = 0: pos unchanged, vel = 0.05*acc (0.5*a*dt)
+    m, pos = orc.gen_refcube(64, seed=7)
+    z = np.zeros((64, 4), np.float32)
+    a = orc.accel_allpairs(orc.LAW_WGSL_BIAS, pos, z, m)
+    p, v, an = orc.step_wgsl_allpairs(orc.LAW_WGSL_BIAS, m, pos, z, z, 1)
+    assert np.array_equal(p[:, :3], pos[:, :3])
+    assert np.array_equal(an, a)
+    assert np.array_equal(v[:, :3], ((np.float32(0.5) * a) * np.float32(0.1))[:, :3])
+
+
+def test_octant_and_weights(orc):
+    # src/octree_maxdepth.rs:210-230 through the key: one level, x->4, y->2, z->1; >= goes high
+    for ci in range(8):
+        x = 200.0 if ci & 4 else 50.0
+        y = 200.0 if ci & 2 else 50.0
+        z = 200.0 if ci & 1 else 50.0
+        assert orc.lib().orc_morton_key(x, y, z, 250.0, 1) == ci
+    assert orc.lib().orc_morton_key(125.0, 125.0, 125.0, 250.0, 1) == 7
+    assert orc.lib().orc_morton_key(np.nextafter(np.float32(125), np.float32(0)), 125.0, 125.0, 250.0, 1) == 3
+    # two levels: (130,130,130) is high at level 0 (centre 125), low at level 1 (centre 187.5)
+    assert orc.lib().orc_morton_key(130.0, 130.0, 130.0, 250.0, 2) == 0b111000
+
+
+def test_node_layout(orc):
+    dt = orc.NODE_DTYPE
+    assert dt.itemsize == 96 == orc.lib().orc_node_size()
+    assert [dt.fields[k][1] for k in ("com", "pos_min", "pos_max", "range", "total_mass", "child", "node_type")] == \
+        [0, 16, 32, 44, 48, 52, 84]
+
+
+def test_tree_small_structures(orc):
+    # 1 body -> 1 LEAFBODY node
+    nodes, leaf, dep, _ = orc.build_octree(p4([[10, 10, 10]]), np.array([2.0], np.float32))
+    assert len(nodes) == 1 and nodes[0]["node_type"] == orc.T_LEAFBODY and nodes[0]["total_mass"] == 2
+    assert nodes[0]["range"] == 0 and leaf[0] == 0 and dep[0] == 0
+    # 2 bodies in different root octants -> 3 nodes; the NEW body's child is allocated first
+    pos = p4([[10, 10, 10], [200, 200, 200]])
+    nodes, leaf, dep, _ = orc.build_octree(pos, np.array([1.0, 3.0], np.float32))
+    assert len(nodes) == 3 and nodes[0]["node_type"] == orc.T_INTERIOR
+    assert nodes[0]["child"][7] == 1 and nodes[0]["child"][0] == 2      # body 1 (new) first
+    assert np.array_equal(nodes[1]["com"], [200, 200, 200]) and np.array_equal(nodes[2]["com"], [10, 10, 10])
+    assert nodes[0]["total_mass"] == 4 and nodes[0]["range"] == 190
+    assert np.allclose(nodes[0]["com"], (10 * 1 + 200 * 3) / 4)
+    assert list(leaf) == [2, 1] and list(dep) == [1, 1]
+    # 2 bodies sharing the octant for 3 levels -> chain of single-child INTERIOR nodes
+    pos = p4([[1, 1, 1], [20, 20, 20]])   # cells: 125 -> 62.5 -> 31.25 -> 15.625 split
+    nodes, leaf, dep, _ = orc.build_octree(pos, np.ones(2, np.float32))
+    types = [int(t) for t in nodes["node_type"]]
+    assert types.count(orc.T_INTERIOR) == 4 and types.count(orc.T_LEAFBODY) == 2 and len(nodes) == 6
+    assert list(dep) == [4, 4]
+    for k in range(3):
+        assert np.count_nonzero(nodes[k]["child"]) == 1
+    assert nodes[0]["range"] == 19
+
+
+def test_tree_leaf_list(orc):
+    # 3 bodies inside one depth-16 cell (cell = 250/65536)
+    cell = 250.0 / 65536.0
+    base = 100 * cell
+    pos = p4([[base + 0.1 * cell] * 3, [base + 0.5 * cell] * 3, [base + 0.9 * cell] * 3])
+    m = np.array([1.0, 2.0, 4.0], np.float32)
+    nodes, leaf, dep, _ = orc.build_octree(pos, m, leaflist_mode=0)
+    ll = [n for n in nodes if n["node_type"] == orc.T_LEAFLIST]
+    assert len(ll) == 1 and ll[0]["child"][1] == 2 and ll[0]["total_mass"] == 7
+    c0, c1 = nodes[ll[0]["child"][0]], nodes[ll[0]["child"][0] + 1]
+    # literal reference behaviour: children are the node's PREVIOUS aggregates A and A+B
+    assert c0["total_mass"] == 1 and np.array_equal(c0["com"], pos[0, :3])
+    assert c1["total_mass"] == 3
+    assert list(dep) == [16, 16, 16] and len(set(leaf)) == 1
+    # children sit at the end of the array (appended after all inserts)
+    assert ll[0]["child"][0] == len(nodes) - 2
+    nodes, _, _, _ = orc.build_octree(pos, m, leaflist_mode=1)
+    ll = [n for n in nodes if n["node_type"] == orc.T_LEAFLIST]
+    assert ll[0]["child"][1] == 3
+    kids = nodes[ll[0]["child"][0]: ll[0]["child"][0] + 3]
+    assert list(kids["total_mass"]) == [1, 2, 4]
+
+
+def test_unbounded_tree_max_depth(orc):
+    # src/octree.rs:58: a leaf created in a cell of half-extent e reports ceil(log2(ceil(250/e)))
+    pos = p4([[1, 1, 1], [20, 20, 20]])
+    nodes, leaf, dep, md = orc.build_octree(pos, np.ones(2, np.float32), variant=1)
+    # leaves at depth 4: half-extent 125/16 -> 250/e = 32 -> log2 = 5 = depth + 1
+    assert md == 5 and nodes[0]["max_depth"] == 5
+    assert sorted(int(x) for x in nodes["node_type"]) == [0, 0, 0, 0, 1, 1]   # is_leaf flags
+
+
+def test_walk_theta_zero_equals_allpairs_and_order(orc):
+    m, pos = orc.gen_refcube(300, seed=3)
+    vel = np.zeros((300, 4), np.float32)
+    vel[:, :3] = 0.3 * (orc.gen_refcube(300, seed=4)[1][:, :3] / 125.0 - 1.0)
+    nodes, _, _, _ = orc.build_octree(pos, m)
+    for law in (orc.LAW_WGSL_BIAS, orc.LAW_PLUMMER):
+        bh, cnt = orc.bh_accel(law, pos, vel, nodes, theta=0.0)
+        ap = orc.accel_allpairs_f64(law, pos, vel, m)
+        err = np.linalg.norm(bh[:, :3] - ap, axis=1) / np.linalg.norm(ap, axis=1)
+        assert err.max() < 2e-5
+        assert cnt["aggregate"] == 0 and cnt["leaf"] == 300 * 300
+    # DFS pops the highest child index first: with 2 bodies in octants 0 and 7 the term of
+    # octant 7 is added first
+    pos2 = p4([[10, 10, 10], [200, 200, 200], [60, 180, 40]])
+    m2 = np.array([1, 2, 3], np.float32)
+    nodes2, _, _, _ = orc.build_octree(pos2, m2)
+    bh, _ = orc.bh_accel(orc.LAW_PLUMMER, pos2, None, nodes2, theta=0.0)
+    ap = orc.accel_allpairs(orc.LAW_PLUMMER, pos2[[1, 2, 0]][::1], None, m2[[1, 2, 0]])
+    # body 2 sits in octant 2 (y high): order of terms for any target is octant 7, 2, 0
+    order = [1, 2, 0]
+    ap = orc.accel_allpairs(orc.LAW_PLUMMER, pos2[order], None, m2[order])
+    assert np.array_equal(bh[order], ap)
+
+
+def test_bh_accuracy_at_theta_half(orc):
+    m, pos = orc.gen_refcube(2000, seed=5)
+    nodes, _, _, _ = orc.build_octree(pos, m)
+    bh, cnt = orc.bh_accel(orc.LAW_PLUMMER, pos, None, nodes, theta=0.5)
+    ap = orc.accel_allpairs_f64(orc.LAW_PLUMMER, pos, None, m)
+    err = np.linalg.norm(bh[:, :3] - ap, axis=1) / np.linalg.norm(ap, axis=1)
+    assert np.median(err) < 3e-2 and cnt["aggregate"] > 0   # monopole error of the reference MAC
+    assert cnt["leaf"] + cnt["aggregate"] < 2000 * 2000 / 2

@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""Headline benchmark: all-pairs gravity step, N = 1,048,576 Plummer-sphere bodies, on N GPUs.
+
+One "step" = forces of all N sources on this rank's targets + velocity-Verlet integration +
+(N > 1 GPUs) the all-gather of the new positions.  Inputs are resident in HBM before timing.
+Prints ONE JSON line (rank 0).  Extra legs, outside the timed region: the reference's own WGSL
+law (acos/pow bias) on the same bodies, and the CPU baseline (the oracle's restatement of
+src/nbody_cpu.rs timed on the host cores, rank 0 at --gpus 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_INTERACTION = {"plummer": 20, "wgsl_bias": 46, "cpu_r6": 20}
+PEAK_FP32_TFLOPS = 157.3  # MI355X FP32 vector peak (256 CU x 256 flop/clk x 2.4 GHz)
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """src/nbody_cpu.rs step (oracle port, OpenMP over targets like the rayon loop) at the
+    reference CPU config: refcube N = 4096."""
+    from oracle import oracle as orc
+    n = 4096
+    m, pos = orc.gen_refcube(n, seed=42)
+    z = np.zeros((n, 4), np.float32)
+    threads = orc.num_threads()
+    t0 = time.time()
+    orc.step_cpu(m, pos, z, z, pos, z, z, 2)
+    per_step = (time.time() - t0) / 2
+    steps = int(max(2, min(100, seconds_budget / max(per_step, 1e-6))))
+    t0 = time.time()
+    orc.step_cpu(m, pos, z, z, pos, z, z, steps)
+    dt = time.time() - t0
+    inter = float(n) * (n - 1) * steps
+    return {"value": inter / dt, "unit": "interactions/s", "cores": threads, "kind": "port",
+            "steps_per_s": steps / dt,
+            "sample": f"refcube N={n}, {steps} steps of the nbody_cpu.rs law (r^-5, unsoftened) + cross-buffer Euler, "
+                      f"{threads} OpenMP threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=1 << 20)
+    ap.add_argument("--law", default="plummer", choices=["plummer", "wgsl_bias"])
+    ap.add_argument("--no-extras", action="store_true", help="skip the WGSL-law and CPU-baseline legs")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import nbody_amd as nb
+    from nbody_amd.shard import ShardedSim, HipShardBackend, shard_range
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n = args.n
+    law = {"plummer": nb.LAW_PLUMMER, "wgsl_bias": nb.LAW_WGSL_BIAS}[args.law]
+    begin, count = shard_range(n, rank, world)
+    masses, pos, vel = nb.gen_plummer(n, seed=42)   # every rank generates the same bodies
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed_run(law_id, steps, warmup):
+        be = HipShardBackend(n, begin, count, local_rank, law=law_id)
+        be.upload(masses, pos, vel)
+        sim = ShardedSim(be, n, rank, world)
+        sim.step_allpairs(warmup)
+        be.sim.set_kernel_timing(True)
+        be.sim.kernel_time()
+        barrier()
+        t0 = time.perf_counter()
+        sim.step_allpairs(steps)
+        barrier()
+        dt = time.perf_counter() - t0
+        kms, launches = be.sim.kernel_time()
+        if world > 1:
+            t = torch.tensor([dt, kms], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt, kms = float(t[0]), float(t[1])
+        be.sim.close()
+        return dt, kms, launches
+
+    dt, kernel_ms, launches = timed_run(law, args.steps, args.warmup)
+    interactions = float(n) * n * args.steps
+    flop = FLOP_PER_INTERACTION[args.law]
+    # the dominant kernel: one launch evaluates count x n interactions on this rank
+    per_launch = float(count) * n
+    achieved = per_launch * flop / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+    out = {
+        "metric": "all-pairs body-body interactions/s at N=1M",
+        "value": interactions / dt,
+        "unit": "interactions/s",
+        "n_gpus": args.gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "steps_per_s": args.steps / dt,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"all-pairs direct sum, N={n} Plummer sphere (a=12.5, equal masses, seed 42), "
+                               f"law={args.law}, velocity-Verlet dt=0.1, targets sharded over {args.gpus} GPU(s), "
+                               "per-step all-gather of positions",
+                   "n_bodies": n, "law": args.law, "parallelism": f"target-shard x{args.gpus}"},
+        "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                     "kernel": "k_allpairs_plummer_pk" if args.law == "plummer" else "k_allpairs",
+                     "kernel_ms": kernel_ms, "launches": launches, "flop_per_interaction": flop,
+                     "note": "FP32 vector (VALU) roofline; the path uses no MFMA and streams 16 B per source"},
+    }
+    if not args.no_extras and args.law == "plummer":
+        # the reference's shader law (src/nbody.wgsl:54-81) on the same bodies, fewer steps
+        wsteps = max(1, min(2, args.steps))
+        wdt, wk, _ = timed_run(nb.LAW_WGSL_BIAS, wsteps, 1)
+        wach = per_launch * FLOP_PER_INTERACTION["wgsl_bias"] / (wk * 1e-3) / 1e12 if wk > 0 else 0.0
+        out["wgsl_bias_law"] = {"value": float(n) * n * wsteps / wdt, "unit": "interactions/s",
+                                "ms_per_step": wdt / wsteps * 1e3, "achieved_tflops": wach,
+                                "frac": wach / PEAK_FP32_TFLOPS, "steps": wsteps}
+    if rank == 0 and args.gpus == 1 and not args.no_extras:
+        try:
+            out["cpu_baseline"] = cpu_baseline()
+        except Exception as e:  # the oracle is a checker, never a dependency of the timed path
+            out["cpu_baseline"] = {"error": str(e)}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

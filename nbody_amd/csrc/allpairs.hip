@@ -6,8 +6,10 @@
 // 16-byte loads (double buffered, one barrier per tile), every lane keeps IPT targets in
 // registers, and the LDS read of a source is a wave-wide broadcast.
 //
-// FP32 VALU bound.  Per PLUMMER interaction the inner loop issues 12 full-rate VALU instructions
-// (3 sub, 3 fma, 3 mul, 3 fma) and one quarter-rate v_rsq_f32.
+// FP32 VALU bound.  Per PLUMMER interaction the inner loop needs 12 VALU lane-operations
+// (3 sub, 3 fma, 3 mul, 3 fma) and one quarter-rate v_rsq_f32; the PLUMMER kernel keeps two
+// targets per packed register pair so that all twelve are v_pk_*_f32 (measured on gfx950:
+// 6 v_pk_fma_f32 + 1 v_rsq_f32 take 34 cycles, 12 v_fma_f32 + 1 v_rsq_f32 take 44).
 #include "ctx.h"
 #include <algorithm>
 #include <cmath>
@@ -75,6 +77,23 @@ __device__ __forceinline__ void interact(const Tgt& t, const float4 s, int jglob
     ax = fmaf(sc, dx, ax);
     ay = fmaf(sc, dy, ay);
     az = fmaf(sc, dz, az);
+}
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// Two targets per packed register pair against one source: every VALU instruction of the
+// PLUMMER term is a v_pk_*_f32 with the source operand broadcast, plus two v_rsq_f32.
+__device__ __forceinline__ void interact_plummer_pk(const f2 px, const f2 py, const f2 pz, const float4 s, float eps2,
+                                                    f2& ax, f2& ay, f2& az) {
+    f2 dx = s.x - px, dy = s.y - py, dz = s.z - pz;
+    f2 r2 = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dz, dz, (f2)eps2)));
+    f2 rinv;
+    rinv.x = __builtin_amdgcn_rsqf(r2.x);
+    rinv.y = __builtin_amdgcn_rsqf(r2.y);
+    f2 sc = (s.w * rinv) * (rinv * rinv);
+    ax = __builtin_elementwise_fma(sc, dx, ax);
+    ay = __builtin_elementwise_fma(sc, dy, ay);
+    az = __builtin_elementwise_fma(sc, dz, az);
 }
 
 // grid.x: target blocks of BLOCK*IPT bodies; grid.y: source slices of j_chunk bodies.
@@ -167,6 +186,87 @@ __global__ __launch_bounds__(BLOCK) void k_allpairs(const float4* __restrict__ p
     for (int k = 0; k < IPT; ++k) {
         int ig = ib + k * BLOCK + tid;
         if (ig < i_end) acc_part[(size_t)blockIdx.y * i_count + (ig - i_begin)] = make_float4(sx[k], sy[k], sz[k], 0.0f);
+    }
+}
+
+// PLUMMER law with two targets per packed register pair (IPT even): same tiling, staging and
+// summation scheme as k_allpairs.
+template <int IPT>
+__global__ __launch_bounds__(BLOCK) void k_allpairs_plummer_pk(const float4* __restrict__ posm,
+                                                                float4* __restrict__ acc_part, int n, int i_begin,
+                                                                int i_count, int j_chunk, float eps2) {
+    static_assert(IPT % 2 == 0, "packed kernel needs an even number of targets per lane");
+    constexpr int H = IPT / 2;
+    __shared__ float4 tile[2][TJ];
+    const int tid = threadIdx.x;
+    const int ib = i_begin + blockIdx.x * (BLOCK * IPT);
+    const int i_end = i_begin + i_count;
+
+    f2 px[H], py[H], pz[H];
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+        float4 p0 = posm[min(ib + (2 * k) * BLOCK + tid, i_end - 1)];
+        float4 p1 = posm[min(ib + (2 * k + 1) * BLOCK + tid, i_end - 1)];
+        px[k] = f2{p0.x, p1.x};
+        py[k] = f2{p0.y, p1.y};
+        pz[k] = f2{p0.z, p1.z};
+    }
+    const int j0 = blockIdx.y * j_chunk;
+    const int j1 = min(n, j0 + j_chunk);
+    const int ntiles = (j1 - j0 + TJ - 1) / TJ;
+
+    f2 sx[H], sy[H], sz[H], cx[H], cy[H], cz[H];
+#pragma unroll
+    for (int k = 0; k < H; ++k) sx[k] = sy[k] = sz[k] = cx[k] = cy[k] = cz[k] = f2{0.0f, 0.0f};
+
+    float4 pre[JL];
+#pragma unroll
+    for (int l = 0; l < JL; ++l) pre[l] = posm[min(j0 + l * BLOCK + tid, j1 - 1)];
+#pragma unroll
+    for (int l = 0; l < JL; ++l) tile[0][l * BLOCK + tid] = pre[l];
+    __syncthreads();
+
+    int buf = 0;
+    for (int tl = 0; tl < ntiles; ++tl) {
+        const int jb = j0 + tl * TJ;
+#pragma unroll
+        for (int l = 0; l < JL; ++l) pre[l] = posm[min(jb + TJ + l * BLOCK + tid, j1 - 1)];
+        const int cnt = min(TJ, j1 - jb);
+        f2 ax[H], ay[H], az[H];
+#pragma unroll
+        for (int k = 0; k < H; ++k) ax[k] = ay[k] = az[k] = f2{0.0f, 0.0f};
+        if (cnt == TJ) {
+#pragma unroll 4
+            for (int jj = 0; jj < TJ; ++jj) {
+                const float4 s = tile[buf][jj];
+#pragma unroll
+                for (int k = 0; k < H; ++k) interact_plummer_pk(px[k], py[k], pz[k], s, eps2, ax[k], ay[k], az[k]);
+            }
+        } else {
+            for (int jj = 0; jj < cnt; ++jj) {
+                const float4 s = tile[buf][jj];
+#pragma unroll
+                for (int k = 0; k < H; ++k) interact_plummer_pk(px[k], py[k], pz[k], s, eps2, ax[k], ay[k], az[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            f2 y, u;
+            y = ax[k] - cx[k]; u = sx[k] + y; cx[k] = (u - sx[k]) - y; sx[k] = u;
+            y = ay[k] - cy[k]; u = sy[k] + y; cy[k] = (u - sy[k]) - y; sy[k] = u;
+            y = az[k] - cz[k]; u = sz[k] + y; cz[k] = (u - sz[k]) - y; sz[k] = u;
+        }
+#pragma unroll
+        for (int l = 0; l < JL; ++l) tile[buf ^ 1][l * BLOCK + tid] = pre[l];
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+        int ig0 = ib + (2 * k) * BLOCK + tid, ig1 = ig0 + BLOCK;
+        float4* dst = acc_part + (size_t)blockIdx.y * i_count;
+        if (ig0 < i_end) dst[ig0 - i_begin] = make_float4(sx[k].x, sy[k].x, sz[k].x, 0.0f);
+        if (ig1 < i_end) dst[ig1 - i_begin] = make_float4(sx[k].y, sy[k].y, sz[k].y, 0.0f);
     }
 }
 
@@ -273,8 +373,22 @@ void launch_ap(nbody_ctx* ctx, const float4* posm, const float4* vel, int slices
                        (int)ctx->i_begin, (int)ctx->i_count, j_chunk, ctx->cfg.eps2);
 }
 
+template <int IPT>
+void launch_ap_pk(nbody_ctx* ctx, const float4* posm, int slices, int j_chunk) {
+    dim3 grid((unsigned)((ctx->i_count + BLOCK * IPT - 1) / (BLOCK * IPT)), (unsigned)slices);
+    hipLaunchKernelGGL((k_allpairs_plummer_pk<IPT>), grid, dim3(BLOCK), 0, ctx->stream, posm, ctx->acc_part, (int)ctx->n,
+                       (int)ctx->i_begin, (int)ctx->i_count, j_chunk, ctx->cfg.eps2);
+}
+
 template <int LAW>
 void launch_ap_ipt(nbody_ctx* ctx, const float4* posm, const float4* vel, int ipt, int slices, int j_chunk) {
+    if (LAW == NBODY_LAW_PLUMMER && ipt >= 2 && !env_int("NBODY_AP_NOPACK", 0)) {
+        switch (ipt) {
+            case 2: launch_ap_pk<2>(ctx, posm, slices, j_chunk); return;
+            case 8: launch_ap_pk<8>(ctx, posm, slices, j_chunk); return;
+            default: launch_ap_pk<4>(ctx, posm, slices, j_chunk); return;
+        }
+    }
     switch (ipt) {
         case 1: launch_ap<LAW, 1>(ctx, posm, vel, slices, j_chunk); break;
         case 2: launch_ap<LAW, 2>(ctx, posm, vel, slices, j_chunk); break;
@@ -330,8 +444,8 @@ int nb_allpairs_forces(nbody_ctx* ctx, const float4* posm_in, const float4* vel_
     int slices = env_int("NBODY_AP_SLICES", 0);
     const int max_slices = (int)std::max<uint64_t>(1, (ctx->n + TJ - 1) / TJ);
     if (slices <= 0) {
-        // aim at >= 8 workgroups per CU in total
-        uint64_t want = (uint64_t)ctx->num_cus * 8;
+        // aim at >= 16 workgroups per CU in total (measured best at N = 65,536 and 1,048,576)
+        uint64_t want = (uint64_t)ctx->num_cus * 16;
         slices = (int)std::min<uint64_t>(64, (want + tblocks - 1) / tblocks);
     }
     slices = std::max(1, std::min(slices, max_slices));

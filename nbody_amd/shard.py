@@ -1,0 +1,98 @@
+"""Target-sharded stepping across the GPUs of one node (one process per GPU).
+
+The reference is single-device.  Here the targets are split into contiguous equal ranges, one
+per rank; every rank integrates its own bodies against ALL sources, then the ranks all-gather
+the packed {x,y,z,m} positions (16 bytes per body) so that each holds the sources of the next
+step.  Velocities and accelerations never leave their rank: the force laws only need the
+target's own velocity (src/nbody.wgsl:74-76).  For Barnes-Hut every rank rebuilds the same
+(replicated) octree from the gathered positions and walks only its own range.
+
+The exchange is one collective per step (`all_gather_into_tensor`, RCCL over xGMI on GPUs); the
+compute backend is injected so that the exchange logic can be exercised with gloo on CPU.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n, rank, world):
+    """Contiguous near-equal split: the first n % world ranks get one body more."""
+    base, extra = divmod(n, world)
+    begin = rank * base + min(rank, extra)
+    return begin, base + (1 if rank < extra else 0)
+
+
+class _DevicePtr:
+    """Exposes a raw device pointer to torch through __cuda_array_interface__."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n, 4), "typestr": "<f4", "data": (ptr, False), "version": 3,
+                                         "strides": None}
+
+
+class HipShardBackend:
+    """One rank's bodies on one MI355X through the C ABI (nbody_amd.NBodySim)."""
+
+    def __init__(self, n, begin, count, device_index, **cfg):
+        from .sim import NBodySim, BUF_POSM
+        torch.cuda.set_device(device_index)
+        self._buf_posm = BUF_POSM
+        stream = torch.cuda.current_stream().cuda_stream
+        self.sim = NBodySim(n, shard_begin=begin, shard_count=count, device=device_index, stream=stream, **cfg)
+        self.n = n
+        self._views = {}
+
+    def upload(self, masses, pos16, vel16=None):
+        self.sim.upload(masses, pos16, vel16)
+
+    def step(self, kind):
+        (self.sim.step_bh if kind == "bh" else self.sim.step_allpairs)(1)
+
+    def posm(self):
+        ptr, _ = self.sim.device_buffer(self._buf_posm)
+        if ptr not in self._views:
+            self._views[ptr] = torch.as_tensor(_DevicePtr(ptr, self.n), device="cuda")
+        return self._views[ptr]
+
+    def download(self):
+        return self.sim.download()
+
+    def sync(self):
+        self.sim.sync()
+
+
+class ShardedSim:
+    def __init__(self, backend, n, rank=None, world=None, group=None):
+        self.backend = backend
+        self.n = n
+        self.group = group
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world is None else world
+        self.begin, self.count = shard_range(n, self.rank, self.world)
+        self._nccl = dist.get_backend(group) == "nccl" if dist.is_initialized() else False
+
+    def exchange(self):
+        """All-gather the current positions: every rank's own range reaches all the others."""
+        if self.world == 1:
+            return
+        full = self.backend.posm()
+        if self.n % self.world == 0:
+            own = full[self.begin:self.begin + self.count]
+            if not self._nccl:
+                own = own.clone()   # gloo: no aliasing of input and output
+            dist.all_gather_into_tensor(full, own, group=self.group)
+        else:
+            for r in range(self.world):
+                b, c = shard_range(self.n, r, self.world)
+                dist.broadcast(full[b:b + c], src=dist.get_global_rank(self.group, r) if self.group else r,
+                               group=self.group)
+
+    def step_allpairs(self, nsteps=1):
+        for _ in range(nsteps):
+            self.backend.step("allpairs")
+            self.exchange()
+
+    def step_bh(self, nsteps=1):
+        for _ in range(nsteps):
+            self.backend.step("bh")
+            self.exchange()

@@ -11,6 +11,7 @@
 // targets per packed register pair so that all twelve are v_pk_*_f32 (measured on gfx950:
 // 6 v_pk_fma_f32 + 1 v_rsq_f32 take 34 cycles, 12 v_fma_f32 + 1 v_rsq_f32 take 44).
 #include "ctx.h"
+#include "laws.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -20,64 +21,6 @@ namespace {
 constexpr int BLOCK = 256;  // 4 wavefronts
 constexpr int TJ = 512;     // sources per LDS tile (8 KiB), two tiles per workgroup
 constexpr int JL = TJ / BLOCK;
-
-struct Tgt {
-    float x, y, z;
-    float vx, vy, vz, vn;  // WGSL_BIAS only: target velocity and its norm
-    int idx;               // global body index (CPU_R6 self test)
-};
-
-// acos(q) for q in [-1,1]: sqrt(1-|q|) * P7(|q|), reflected for q < 0 (Abramowitz & Stegun
-// 4.4.46, |error| <= 2e-8 before f32 rounding).
-__device__ __forceinline__ float fast_acos(float q) {
-    float a = fminf(fabsf(q), 1.0f);
-    float p = -0.0012624911f;
-    p = fmaf(p, a, 0.0066700901f);
-    p = fmaf(p, a, -0.0170881256f);
-    p = fmaf(p, a, 0.0308918810f);
-    p = fmaf(p, a, -0.0501743046f);
-    p = fmaf(p, a, 0.0889789874f);
-    p = fmaf(p, a, -0.2145988016f);
-    p = fmaf(p, a, 1.5707963050f);
-    float r = __builtin_amdgcn_sqrtf(1.0f - a) * p;
-    return q < 0.0f ? 3.14159265358979f - r : r;
-}
-
-// One source term added to (ax,ay,az).  G is applied once per target afterwards.
-// SELF: compare the source's global index with the target's (CPU_R6 skips n2 == n,
-// src/nbody_cpu.rs:335).
-template <int LAW, bool SELF>
-__device__ __forceinline__ void interact(const Tgt& t, const float4 s, int jglob, float eps2, float& ax, float& ay,
-                                         float& az) {
-    float dx = s.x - t.x, dy = s.y - t.y, dz = s.z - t.z;
-    float sc;
-    if (LAW == NBODY_LAW_CPU_R6) {
-        // src/nbody_cpu.rs:337-340: m*d / (d.d)^3
-        float r2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
-        float r6 = r2 * r2 * r2;
-        sc = s.w * __builtin_amdgcn_rcpf(r6);
-        if (SELF) sc = (jglob == t.idx) ? 0.0f : sc;
-    } else if (LAW == NBODY_LAW_PLUMMER) {
-        // src/nbody.wgsl:56-65 without :74-79
-        float r2 = fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, eps2)));
-        float rinv = __builtin_amdgcn_rsqf(r2);
-        sc = (s.w * rinv) * (rinv * rinv);
-    } else {
-        // src/nbody.wgsl:56-79
-        float r2u = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
-        float dist = __builtin_amdgcn_sqrtf(r2u);
-        float rinv = __builtin_amdgcn_rsqf(r2u + eps2);
-        sc = (s.w * rinv) * (rinv * rinv);
-        float vd = fmaf(t.vx, dx, fmaf(t.vy, dy, t.vz * dz));
-        float q = vd * __builtin_amdgcn_rcpf(fmaf(dist, t.vn, 1.0f));
-        float b = fast_acos(q);
-        // pow(b, 0.15) = exp2(0.15*log2(b)); b == 0 gives exp2(-inf) = 0
-        sc *= __builtin_amdgcn_exp2f(0.15f * __builtin_amdgcn_logf(b));
-    }
-    ax = fmaf(sc, dx, ax);
-    ay = fmaf(sc, dy, ay);
-    az = fmaf(sc, dz, az);
-}
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 

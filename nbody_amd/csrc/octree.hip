@@ -1,11 +1,912 @@
-// placeholder until the octree build/walk kernels land
+// Barnes-Hut on gfx950: octree build from Morton keys and per-wavefront traversal.
+//
+// Replaces OctreeNode::new_tree (src/octree_maxdepth.rs:26-186; single-threaded, on the host,
+// every frame) and the traversal of src/nbodybh.wgsl:63-161.
+//
+// The reference inserts bodies one by one; the tree it ends with is a function of the body SET:
+// a cell is a node iff its parent holds >= 2 bodies, a cell with one body is a LEAFBODY, a
+// depth-cap cell with >= 2 bodies is a LEAFLIST.  Build here:
+//   1. k_morton      key = the octant path of the reference's own comparison descent (bit-exact)
+//   2. radix sort    (key, body index), 8-bit digits, stable => equal keys stay in index order
+//   3. k_prefix      per sorted body: common-prefix depth with both neighbours => the range of
+//                    levels [lo, top] at which it is the first body of an existing cell
+//   4. row scans     breadth-first numbering: node id = level_start[d] + rank of the cell in d
+//   5. k_emit        writes the nodes, links each into its parent's child slot (octant order)
+//   6. k_leaflist    depth-cap cells: sequential prefix aggregates in index order (literal
+//                    reference arithmetic, src/octree_maxdepth.rs:91-136)
+//   7. k_aggregate   bottom-up, one launch per level: mass, centre of mass, bounds, range
+// Node numbering differs from the reference's allocation order; the cell set, every body's leaf,
+// bounds and range are identical, masses/centres agree to rounding (different summation order).
+//
+// Traversal: one wavefront walks 64 Morton-adjacent bodies with ONE shared stack of
+// (node, lane mask) entries in LDS.  A node is opened if any lane needs it; lanes that accepted
+// an ancestor are masked out of its subtree, so each lane sees exactly the node sequence of the
+// reference's private depth-first stack (children pushed ascending, popped highest first).
+// Node records are 64 bytes and are fetched with wave-uniform (scalar) loads.
 #include "ctx.h"
-struct Octree { int dummy; };
-int nb_tree_create(nbody_ctx*) { return NBODY_OK; }
-void nb_tree_destroy(nbody_ctx*) {}
-int nb_tree_build(nbody_ctx* ctx, const float4*) { return nb_fail(ctx, NBODY_ERR_STATE, "octree build not available"); }
-int nb_tree_walk(nbody_ctx* ctx, const float4*, const float4*, float4*) { return nb_fail(ctx, NBODY_ERR_STATE, "octree walk not available"); }
-int nb_tree_download(nbody_ctx* ctx, nbody_octree_node*, uint64_t, uint64_t*) { return nb_fail(ctx, NBODY_ERR_STATE, "no octree"); }
-int nb_tree_upload(nbody_ctx* ctx, const nbody_octree_node*, uint64_t) { return nb_fail(ctx, NBODY_ERR_STATE, "no octree"); }
-int nb_tree_keys(nbody_ctx* ctx, uint64_t*, uint8_t*, uint32_t*) { return nb_fail(ctx, NBODY_ERR_STATE, "no octree"); }
-int nb_tree_device_nodes(nbody_ctx* ctx, void**, size_t*) { return nb_fail(ctx, NBODY_ERR_STATE, "no octree"); }
+#include "laws.h"
+#include <algorithm>
+#include <cstring>
+#include <cmath>
+
+namespace {
+
+constexpr int NCNT = 18;       // level counters 0..16 + leaf-list members
+constexpr int LIST_ROW = 17;
+constexpr uint32_t NO_NODE = 0xffffffffu;
+
+// Traversal record (64 B): one s_load_dwordx16 per visit.
+struct WNode {
+    float cx, cy, cz, mass;
+    float range;
+    uint32_t type;
+    uint32_t depth;
+    uint32_t head;  // sorted rank of the first body of the cell (build bookkeeping)
+    uint32_t child[8];
+};
+static_assert(sizeof(WNode) == 64, "walk node layout");
+
+}  // namespace
+
+struct Octree {
+    uint64_t n = 0;
+    uint32_t D = 16;
+    // sort buffers
+    uint64_t* keys[2] = {nullptr, nullptr};
+    uint32_t* idx[2] = {nullptr, nullptr};
+    int sorted = 0;  // which buffer holds the sorted result
+    uint8_t* lo = nullptr;
+    uint8_t* top = nullptr;
+    uint8_t* flags = nullptr;
+    uint32_t* body_node = nullptr;  // per sorted rank: node of the body's leaf (NO_NODE for list members)
+    uint32_t* rs_counts = nullptr;  // [256][rs_nb]
+    uint32_t rs_nb = 0;
+    uint32_t* row_total = nullptr;  // [256]
+    uint32_t* row_base = nullptr;   // [257]
+    uint32_t* blk = nullptr;        // [NCNT][pf_nb]
+    uint32_t pf_nb = 0;
+    uint32_t* lvl_total = nullptr;  // [NCNT]
+    uint32_t* lvl_start = nullptr;  // [NCNT+1]
+    uint32_t h_lvl_start[NCNT + 1] = {0};
+    // nodes
+    WNode* nodes = nullptr;
+    float4* bmin = nullptr;
+    float4* bmax = nullptr;
+    uint64_t cap_nodes = 0;
+    uint64_t n_nodes = 0;
+    bool have_tree = false;
+    bool built = false;  // tree came from nb_tree_build (keys/order valid)
+    // export buffer
+    nbody_octree_node* export_buf = nullptr;
+    uint64_t export_cap = 0;
+    // walk
+    uint32_t* shard_order = nullptr;  // sorted ranks' body indices restricted to the shard
+    uint64_t* walk_counters = nullptr;  // [8]
+    uint32_t* err_flag = nullptr;
+};
+
+namespace {
+
+// ---- 1. Morton keys -----------------------------------------------------------------------
+// The reference's descent, literally (src/octree_maxdepth.rs:139,142,156,210-230): compare with
+// the cell centre (>= goes high; x->4, y->2, z->1), halve the extent, move the centre.
+__global__ void k_morton(const float4* __restrict__ posm, uint32_t n, float world, int D, uint64_t* __restrict__ keys,
+                         uint32_t* __restrict__ idx) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 p = posm[i];
+    float ext = world / 2.0f;
+    float cx = ext, cy = ext, cz = ext;
+    uint64_t key = 0;
+    for (int l = 0; l < D; ++l) {
+        ext = ext / 2.0f;
+        uint32_t ci = 0;
+        float wx = -1.0f, wy = -1.0f, wz = -1.0f;
+        if (p.x >= cx) { ci |= 4u; wx = 1.0f; }
+        if (p.y >= cy) { ci |= 2u; wy = 1.0f; }
+        if (p.z >= cz) { ci |= 1u; wz = 1.0f; }
+        key = (key << 3) | ci;
+        cx = cx + (ext * wx);
+        cy = cy + (ext * wy);
+        cz = cz + (ext * wz);
+    }
+    keys[i] = key;
+    idx[i] = i;
+}
+
+// ---- 2. LSD radix sort, 8-bit digits ------------------------------------------------------
+constexpr int RS_THREADS = 256;
+constexpr int RS_ITEMS = 8;
+constexpr int RS_TILE = RS_THREADS * RS_ITEMS;
+
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint64_t* __restrict__ keys, uint32_t n, int shift,
+                                                        uint32_t* __restrict__ counts, uint32_t nb) {
+    __shared__ uint32_t h[256];
+    const int tid = threadIdx.x;
+    h[tid] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * RS_TILE;
+#pragma unroll
+    for (int it = 0; it < RS_ITEMS; ++it) {
+        uint32_t i = base + it * RS_THREADS + tid;
+        if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    counts[(size_t)tid * nb + blockIdx.x] = h[tid];
+}
+
+// Exclusive scan of each row of a [rows][nb] matrix in place (one workgroup per row), row sums
+// to row_total.
+__global__ __launch_bounds__(256) void k_rowscan(uint32_t* __restrict__ m, uint32_t nb, uint32_t* __restrict__ row_total) {
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t carry_s;
+    uint32_t* p = m + (size_t)blockIdx.x * nb;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nb; base += 1024) {
+        uint32_t i0 = base + tid * 4;
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (i0 + k < nb) ? p[i0 + k] : 0u;
+        uint32_t s = v[0] + v[1] + v[2] + v[3];
+        uint32_t x = s;  // inclusive wave scan
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        uint32_t carry = carry_s;
+        uint32_t excl = carry + woff + x - s;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (i0 + k < nb) p[i0 + k] = excl;
+            excl += v[k];
+        }
+        __syncthreads();
+        if (tid == 255) carry_s = carry + woff + x;
+        __syncthreads();
+    }
+    if (tid == 0) row_total[blockIdx.x] = carry_s;
+}
+
+// Exclusive scan of rows (<= 256) totals; out[rows] = grand total.
+__global__ __launch_bounds__(256) void k_scan_small(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int rows) {
+    __shared__ uint32_t s[257];
+    const int tid = threadIdx.x;
+    s[tid] = tid < rows ? in[tid] : 0u;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t acc = 0;
+        for (int r = 0; r < rows; ++r) {
+            uint32_t v = s[r];
+            s[r] = acc;
+            acc += v;
+        }
+        s[rows] = acc;
+    }
+    __syncthreads();
+    if (tid <= rows) out[tid] = s[tid];
+    if (tid == 0 && rows == 256) out[256] = s[256];
+}
+
+__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t* __restrict__ keys_in,
+                                                           const uint32_t* __restrict__ idx_in,
+                                                           uint64_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out,
+                                                           uint32_t n, int shift, const uint32_t* __restrict__ counts,
+                                                           const uint32_t* __restrict__ row_base, uint32_t nb) {
+    __shared__ uint32_t running[256];
+    __shared__ uint32_t wcnt[4][256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    running[tid] = row_base[tid] + counts[(size_t)tid * nb + blockIdx.x];
+    const uint32_t base = blockIdx.x * RS_TILE;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int it = 0; it < RS_ITEMS; ++it) {
+        const uint32_t i = base + it * RS_THREADS + tid;
+        const bool valid = i < n;
+        uint64_t key = 0;
+        uint32_t val = 0, d = 0;
+        if (valid) {
+            key = keys_in[i];
+            val = idx_in[i];
+            d = (uint32_t)(key >> shift) & 255u;
+        }
+        wcnt[0][tid] = 0;
+        wcnt[1][tid] = 0;
+        wcnt[2][tid] = 0;
+        wcnt[3][tid] = 0;
+        __syncthreads();
+        // lanes of this wavefront holding the same digit
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        const uint32_t rank = __popcll(peers & lt);
+        if (valid && rank == 0) wcnt[wave][d] = __popcll(peers);
+        __syncthreads();
+        if (valid) {
+            uint32_t pos = running[d] + rank;
+            for (int w = 0; w < wave; ++w) pos += wcnt[w][d];
+            keys_out[pos] = key;
+            idx_out[pos] = val;
+        }
+        __syncthreads();
+        running[tid] += wcnt[0][tid] + wcnt[1][tid] + wcnt[2][tid] + wcnt[3][tid];
+        __syncthreads();
+    }
+}
+
+// ---- 3. neighbour prefixes ----------------------------------------------------------------
+// Levels (0..D) two keys share: D if equal.
+__device__ __forceinline__ int common_levels(uint64_t a, uint64_t b, int D) {
+    uint64_t x = a ^ b;
+    if (x == 0) return D;
+    int hb = 63 - __clzll((long long)x);
+    return D - 1 - hb / 3;
+}
+
+// flags: bit0 = contributes a leaf-list member node, bit1 = first body of a depth-cap cell
+// holding >= 2 bodies, bit2 = member of such a cell.
+__global__ __launch_bounds__(256) void k_prefix(const uint64_t* __restrict__ keys, uint32_t n, int D, int list_mode,
+                                                uint8_t* __restrict__ lo, uint8_t* __restrict__ top,
+                                                uint8_t* __restrict__ flags, uint32_t* __restrict__ blk, uint32_t nb) {
+    __shared__ uint32_t sh[NCNT];
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid < NCNT) sh[tid] = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256 + tid;
+    const bool valid = i < n;
+    int l = 1, t = 0;
+    uint32_t f = 0;
+    if (valid) {
+        const uint64_t k = keys[i];
+        const int Lp = (i == 0) ? -1 : common_levels(keys[i - 1], k, D);
+        const int Ln = (i + 1 == n) ? -1 : common_levels(k, keys[i + 1], D);
+        l = Lp + 1;
+        t = min(D, max(Lp, Ln) + 1);
+        const bool inlist = (Lp == D) || (Ln == D);
+        const bool member = list_mode ? inlist : (inlist && Ln == D);
+        f = (member ? 1u : 0u) | ((Lp < D && Ln == D) ? 2u : 0u) | (inlist ? 4u : 0u);
+        lo[i] = (uint8_t)l;
+        top[i] = (uint8_t)t;
+        flags[i] = (uint8_t)f;
+    }
+#pragma unroll
+    for (int d = 0; d < NCNT; ++d) {
+        const bool has = valid && ((d < LIST_ROW) ? (l <= d && d <= t) : (f & 1u));
+        const unsigned long long b = __ballot(has);
+        if (lane == 0 && b) atomicAdd(&sh[d], (uint32_t)__popcll(b));
+    }
+    __syncthreads();
+    if (tid < NCNT) blk[(size_t)tid * nb + blockIdx.x] = sh[tid];
+}
+
+// ---- 5. emit nodes ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_emit(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idx,
+                                              const float4* __restrict__ posm, uint32_t n, int D,
+                                              const uint8_t* __restrict__ lo, const uint8_t* __restrict__ top,
+                                              const uint8_t* __restrict__ flags, const uint32_t* __restrict__ blk,
+                                              uint32_t nb, const uint32_t* __restrict__ lvl_start, WNode* __restrict__ nodes,
+                                              float4* __restrict__ bmin, float4* __restrict__ bmax,
+                                              uint32_t* __restrict__ body_node, uint32_t cap_nodes,
+                                              uint32_t* __restrict__ err_flag) {
+    __shared__ uint32_t wtot[NCNT][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t i = blockIdx.x * 256 + tid;
+    const bool valid = i < n;
+    int l = 1, t = 0;
+    uint32_t f = 0;
+    uint64_t key = 0;
+    if (valid) {
+        l = lo[i];
+        t = top[i];
+        f = flags[i];
+        key = keys[i];
+    }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const unsigned long long le = lt | (1ull << lane);
+#pragma unroll
+    for (int d = 0; d < NCNT; ++d) {
+        const bool has = valid && ((d < LIST_ROW) ? (l <= d && d <= t) : (f & 1u));
+        const unsigned long long b = __ballot(has);
+        if (lane == 0) wtot[d][wave] = (uint32_t)__popcll(b);
+    }
+    __syncthreads();
+    // rank among leaf-list members (for the first member of a list)
+    uint32_t list_first = 0;
+    {
+        const unsigned long long b = __ballot(valid && (f & 1u));
+        uint32_t base = lvl_start[LIST_ROW] + blk[(size_t)LIST_ROW * nb + blockIdx.x];
+        for (int w = 0; w < wave; ++w) base += wtot[LIST_ROW][w];
+        list_first = base + (uint32_t)__popcll(b & lt);
+    }
+    float4 p = make_float4(0, 0, 0, 0);
+    if (valid && l <= t) p = posm[idx[i]];
+    if (valid && l > t) body_node[i] = NO_NODE;
+    uint32_t prev_incl = 0;
+    for (int d = 0; d <= D; ++d) {
+        const bool has = valid && l <= d && d <= t;
+        const unsigned long long b = __ballot(has);
+        uint32_t base = lvl_start[d] + blk[(size_t)d * nb + blockIdx.x];
+        for (int w = 0; w < wave; ++w) base += wtot[d][w];
+        const uint32_t id = base + (uint32_t)__popcll(b & lt);
+        const uint32_t incl = base + (uint32_t)__popcll(b & le);
+        if (has) {
+            if (id >= cap_nodes) {
+                *err_flag = 1;
+            } else {
+                uint32_t type;
+                if (d < t) type = NBODY_NODE_INTERIOR;
+                else if (f & 2u) type = NBODY_NODE_LEAFLIST;  // d == t == D, first of >= 2 bodies
+                else type = NBODY_NODE_LEAFBODY;
+                WNode& nd = nodes[id];
+                nd.type = type;
+                nd.depth = (uint32_t)d;
+                nd.head = i;
+                if (type == NBODY_NODE_LEAFBODY) {  // src/octree_maxdepth.rs:75-86
+                    nd.cx = p.x;
+                    nd.cy = p.y;
+                    nd.cz = p.z;
+                    nd.mass = p.w;
+                    nd.range = 0.0f;
+                    bmin[id] = make_float4(p.x, p.y, p.z, 0.0f);
+                    bmax[id] = make_float4(p.x, p.y, p.z, 0.0f);
+                } else if (type == NBODY_NODE_LEAFLIST) {
+                    nd.child[0] = list_first;  // child[1] (the count) is written by k_leaflist
+                }
+                if (d > 0) {
+                    const uint32_t parent = prev_incl - 1;  // last cell of level d-1 starting at or before i
+                    const uint32_t oct = (uint32_t)(key >> (3 * (D - d))) & 7u;
+                    nodes[parent].child[oct] = id;
+                }
+                if (d == t) body_node[i] = id;
+            }
+        }
+        prev_incl = incl;
+    }
+}
+
+// ---- 6. depth-cap cells -------------------------------------------------------------------
+// One thread per cell: the reference's aggregate recurrence over the cell's bodies in index
+// order, and the list members it creates (src/octree_maxdepth.rs:91-136).
+__global__ void k_leaflist(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idx,
+                           const float4* __restrict__ posm, uint32_t n, int list_mode, const uint8_t* __restrict__ flags,
+                           const uint32_t* __restrict__ body_node, WNode* __restrict__ nodes, float4* __restrict__ bmin,
+                           float4* __restrict__ bmax, uint32_t cap_nodes, uint32_t D) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !(flags[i] & 2u)) return;
+    const uint32_t id = body_node[i];
+    if (id >= cap_nodes) return;
+    WNode& nd = nodes[id];
+    const uint64_t key = keys[i];
+    uint32_t member = nd.child[0];
+    uint32_t count = 0;
+    float4 a = posm[idx[i]];  // aggregate: xyz = centre of mass, w = mass
+    float mnx = a.x, mny = a.y, mnz = a.z, mxx = a.x, mxy = a.y, mxz = a.z;
+    auto put = [&](float4 q) {
+        if (member < cap_nodes) {
+            WNode& c = nodes[member];
+            c.cx = q.x; c.cy = q.y; c.cz = q.z; c.mass = q.w;
+            c.range = 0.0f;
+            c.type = NBODY_NODE_LEAFBODY;
+            c.depth = D;  // src/octree_maxdepth.rs:132 inserts the member with depth 0; recorded as the cell's
+            c.head = i;
+            bmin[member] = make_float4(q.x, q.y, q.z, 0.0f);
+            bmax[member] = make_float4(q.x, q.y, q.z, 0.0f);
+        }
+        ++member;
+        ++count;
+    };
+    if (list_mode) put(a);
+    for (uint32_t j = i + 1; j < n && keys[j] == key; ++j) {
+        const float4 b = posm[idx[j]];
+        if (!list_mode) put(a);  // literal: the member is the PREVIOUS aggregate (node_a_*)
+        else put(b);
+        const float tm = a.w + b.w;
+        a.x = ((a.x * a.w) + (b.x * b.w)) / tm;
+        a.y = ((a.y * a.w) + (b.y * b.w)) / tm;
+        a.z = ((a.z * a.w) + (b.z * b.w)) / tm;
+        a.w = tm;
+        mnx = fminf(mnx, b.x); mny = fminf(mny, b.y); mnz = fminf(mnz, b.z);
+        mxx = fmaxf(mxx, b.x); mxy = fmaxf(mxy, b.y); mxz = fmaxf(mxz, b.z);
+    }
+    nd.cx = a.x; nd.cy = a.y; nd.cz = a.z; nd.mass = a.w;
+    nd.range = fmaxf(mxx - mnx, fmaxf(mxy - mny, mxz - mnz));
+    nd.child[1] = count;
+    bmin[id] = make_float4(mnx, mny, mnz, 0.0f);
+    bmax[id] = make_float4(mxx, mxy, mxz, 0.0f);
+}
+
+// ---- 7. aggregates ------------------------------------------------------------------------
+__global__ void k_aggregate(WNode* __restrict__ nodes, float4* __restrict__ bmin, float4* __restrict__ bmax,
+                            uint32_t first, uint32_t count) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= count) return;
+    const uint32_t id = first + r;
+    WNode& nd = nodes[id];
+    if (nd.type != NBODY_NODE_INTERIOR) return;
+    float M = 0.0f, wx = 0.0f, wy = 0.0f, wz = 0.0f;
+    float mnx = INFINITY, mny = INFINITY, mnz = INFINITY, mxx = -INFINITY, mxy = -INFINITY, mxz = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t c = nd.child[k];
+        if (c == 0) continue;
+        const WNode& ch = nodes[c];
+        M += ch.mass;
+        wx += ch.cx * ch.mass;
+        wy += ch.cy * ch.mass;
+        wz += ch.cz * ch.mass;
+        const float4 lo = bmin[c], hi = bmax[c];
+        mnx = fminf(mnx, lo.x); mny = fminf(mny, lo.y); mnz = fminf(mnz, lo.z);
+        mxx = fmaxf(mxx, hi.x); mxy = fmaxf(mxy, hi.y); mxz = fmaxf(mxz, hi.z);
+    }
+    nd.mass = M;
+    nd.cx = wx / M;
+    nd.cy = wy / M;
+    nd.cz = wz / M;
+    nd.range = fmaxf(mxx - mnx, fmaxf(mxy - mny, mxz - mnz));  // src/octree_maxdepth.rs:101
+    bmin[id] = make_float4(mnx, mny, mnz, 0.0f);
+    bmax[id] = make_float4(mxx, mxy, mxz, 0.0f);
+}
+
+// ---- export / import (96-byte reference layout) ---------------------------------------------
+__global__ void k_export(const WNode* __restrict__ nodes, const float4* __restrict__ bmin, const float4* __restrict__ bmax,
+                         uint32_t count, nbody_octree_node* __restrict__ out) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= count) return;
+    const WNode nd = nodes[id];
+    const float4 lo = bmin[id], hi = bmax[id];
+    nbody_octree_node o;
+    o.center_of_mass[0] = nd.cx; o.center_of_mass[1] = nd.cy; o.center_of_mass[2] = nd.cz; o._pad0 = 0.0f;
+    o.pos_min[0] = lo.x; o.pos_min[1] = lo.y; o.pos_min[2] = lo.z; o._pad1 = 0.0f;
+    o.pos_max[0] = hi.x; o.pos_max[1] = hi.y; o.pos_max[2] = hi.z;
+    o.range = nd.range;
+    o.total_mass = nd.mass;
+    for (int k = 0; k < 8; ++k) o.child_indices[k] = nd.child[k];
+    o.node_type = nd.type;
+    o.depth = nd.depth;
+    o._pad2 = 0;
+    out[id] = o;
+}
+
+__global__ void k_import(const nbody_octree_node* __restrict__ in, uint32_t count, WNode* __restrict__ nodes,
+                         float4* __restrict__ bmin, float4* __restrict__ bmax) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= count) return;
+    const nbody_octree_node o = in[id];
+    WNode nd;
+    nd.cx = o.center_of_mass[0]; nd.cy = o.center_of_mass[1]; nd.cz = o.center_of_mass[2];
+    nd.mass = o.total_mass;
+    nd.range = o.range;
+    nd.type = o.node_type;
+    nd.depth = o.depth;
+    nd.head = 0;
+    for (int k = 0; k < 8; ++k) nd.child[k] = o.child_indices[k];
+    nodes[id] = nd;
+    bmin[id] = make_float4(o.pos_min[0], o.pos_min[1], o.pos_min[2], 0.0f);
+    bmax[id] = make_float4(o.pos_max[0], o.pos_max[1], o.pos_max[2], 0.0f);
+}
+
+// Body indices of the sorted order restricted to [i_begin, i_end): stable compaction, one
+// workgroup (the shard lists are rebuilt once per step; n / 1024 trips).
+__global__ __launch_bounds__(1024) void k_compact_order(const uint32_t* __restrict__ idx, uint32_t n, uint32_t i_begin,
+                                                         uint32_t i_end, uint32_t* __restrict__ out) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t r = base + tid;
+        uint32_t b = 0;
+        bool keep = false;
+        if (r < n) {
+            b = idx[r];
+            keep = b >= i_begin && b < i_end;
+        }
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) wsum[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t off = carry_s;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        if (keep) out[off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = b;
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t tot = 0;
+            for (int w = 0; w < 16; ++w) tot += wsum[w];
+            carry_s += tot;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- traversal ----------------------------------------------------------------------------
+constexpr int WALK_STACK = 160;  // >= 8 children x 17 levels + root
+
+template <int LAW, bool COUNT>
+__global__ __launch_bounds__(256) void k_walk(const WNode* __restrict__ nodes, const uint32_t* __restrict__ order,
+                                              uint32_t m, uint32_t i_begin, const float4* __restrict__ posm,
+                                              const float4* __restrict__ vel, float4* __restrict__ acc_out, float G,
+                                              float eps2, float theta, unsigned long long* __restrict__ counters,
+                                              uint32_t* __restrict__ err_flag) {
+    __shared__ uint32_t st_id[4][WALK_STACK];
+    __shared__ unsigned long long st_mask[4][WALK_STACK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t r = blockIdx.x * 256 + tid;
+    const bool valid = r < m;
+    const uint32_t b = valid ? (order ? order[r] : i_begin + r) : 0u;
+    Tgt t;
+    {
+        const float4 p = posm[b];
+        t.x = p.x; t.y = p.y; t.z = p.z;
+        t.idx = (int)b;
+        t.vx = t.vy = t.vz = t.vn = 0.0f;
+        if (LAW == NBODY_LAW_WGSL_BIAS) {
+            const float4 v = vel[b];
+            t.vx = v.x; t.vy = v.y; t.vz = v.z;
+            t.vn = sqrtf(fmaf(v.x, v.x, fmaf(v.y, v.y, v.z * v.z)));
+        }
+    }
+    float ax = 0.0f, ay = 0.0f, az = 0.0f;
+    uint32_t n_visit = 0, n_leaf = 0, n_agg = 0, n_wave = 0, max_top = 0;
+
+    uint32_t* sid = st_id[wave];
+    unsigned long long* smask = st_mask[wave];
+    int top = 0;
+    const unsigned long long all = __ballot(valid);
+    if (all) {
+        sid[0] = 0;
+        smask[0] = all;
+        top = 1;
+    }
+    while (top > 0) {
+        --top;
+        const uint32_t id = __builtin_amdgcn_readfirstlane(sid[top]);
+        const unsigned long long mk = smask[top];
+        const uint32_t mlo = __builtin_amdgcn_readfirstlane((uint32_t)mk);
+        const uint32_t mhi = __builtin_amdgcn_readfirstlane((uint32_t)(mk >> 32));
+        const unsigned long long mask = ((unsigned long long)mhi << 32) | mlo;
+        const bool active = (mask >> lane) & 1ull;
+        const WNode nd = nodes[id];
+        if (COUNT) {
+            n_wave += (lane == 0);
+            n_visit += active;
+        }
+        const float4 src = make_float4(nd.cx, nd.cy, nd.cz, nd.mass);
+        if (nd.type == NBODY_NODE_LEAFBODY) {  // src/nbodybh.wgsl:76-102
+            if (active) {
+                interact<LAW, false, true>(t, src, 0, eps2, ax, ay, az);
+                if (COUNT) ++n_leaf;
+            }
+        } else {
+            // src/nbodybh.wgsl:104-106: d / r < theta with r = distance(pos, com)
+            const float dx = t.x - nd.cx, dy = t.y - nd.cy, dz = t.z - nd.cz;
+            const float rr = sqrtf(((dx * dx) + (dy * dy)) + (dz * dz));
+            const bool accept = (nd.range / rr) < theta;
+            if (active && accept) {
+                interact<LAW, false, true>(t, src, 0, eps2, ax, ay, az);
+                if (COUNT) ++n_agg;
+            }
+            const unsigned long long open = __ballot(active && !accept);
+            if (open) {
+                if (nd.type == NBODY_NODE_LEAFLIST) {
+                    // src/nbodybh.wgsl:137-146: members pushed ascending (at least one), so they are
+                    // popped next, highest first; they are LEAFBODY nodes and push nothing themselves
+                    const uint32_t first = nd.child[0];
+                    const uint32_t cnt = max(nd.child[1], 1u);
+                    const bool mine = (open >> lane) & 1ull;
+                    for (uint32_t k = cnt; k-- > 0;) {
+                        const WNode c = nodes[first + k];
+                        if (COUNT) {
+                            n_wave += (lane == 0);
+                            n_visit += mine;
+                        }
+                        if (mine) {
+                            interact<LAW, false, true>(t, make_float4(c.cx, c.cy, c.cz, c.mass), 0, eps2, ax, ay, az);
+                            if (COUNT) ++n_leaf;
+                        }
+                    }
+                } else {  // src/nbodybh.wgsl:148-157
+                    if (top + 8 > WALK_STACK) {
+                        if (lane == 0) *err_flag = 2;
+                        break;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const uint32_t c = nd.child[k];
+                        if (c != 0u) {
+                            sid[top] = c;
+                            smask[top] = open;
+                            ++top;
+                        }
+                    }
+                    if (COUNT) max_top = max(max_top, (uint32_t)top);
+                }
+            }
+        }
+    }
+    if (valid) acc_out[b] = make_float4(G * ax, G * ay, G * az, 0.0f);
+    if (COUNT) {
+        atomicAdd(&counters[0], (unsigned long long)n_visit);
+        atomicAdd(&counters[1], (unsigned long long)n_leaf);
+        atomicAdd(&counters[2], (unsigned long long)n_agg);
+        atomicAdd(&counters[3], (unsigned long long)n_wave);
+        atomicMax(&counters[4], (unsigned long long)max_top);
+    }
+}
+
+int ensure_nodes(nbody_ctx* ctx, Octree* T, uint64_t need) {
+    if (need <= T->cap_nodes) return NBODY_OK;
+    uint64_t cap = std::max<uint64_t>(need + need / 4 + 1024, 2 * T->n + 1024);
+    if (cap > 0xfffffff0ull) return nb_fail(ctx, NBODY_ERR_CAPACITY, "octree needs more than 2^32 nodes");
+    if (T->nodes) NB_HIP(ctx, hipFree(T->nodes));
+    if (T->bmin) NB_HIP(ctx, hipFree(T->bmin));
+    if (T->bmax) NB_HIP(ctx, hipFree(T->bmax));
+    T->nodes = nullptr;
+    T->bmin = T->bmax = nullptr;
+    T->cap_nodes = 0;
+    NB_HIP(ctx, hipMalloc(&T->nodes, cap * sizeof(WNode)));
+    NB_HIP(ctx, hipMalloc(&T->bmin, cap * sizeof(float4)));
+    NB_HIP(ctx, hipMalloc(&T->bmax, cap * sizeof(float4)));
+    T->cap_nodes = cap;
+    return NBODY_OK;
+}
+
+int check_err_flag(nbody_ctx* ctx, Octree* T, const char* what) {
+    uint32_t h = 0;
+    NB_HIP(ctx, hipMemcpyAsync(&h, T->err_flag, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (h) {
+        NB_HIP(ctx, hipMemsetAsync(T->err_flag, 0, sizeof(uint32_t), ctx->stream));
+        return nb_fail(ctx, NBODY_ERR_CAPACITY,
+                       std::string(what) + (h == 2 ? ": traversal stack overflow" : ": node capacity exceeded"));
+    }
+    return NBODY_OK;
+}
+
+template <int LAW>
+void launch_walk(nbody_ctx* ctx, Octree* T, const uint32_t* order, uint32_t m, const float4* posm, const float4* vel,
+                 float4* acc_out) {
+    dim3 grid((m + 255) / 256);
+    if (ctx->counting)
+        hipLaunchKernelGGL((k_walk<LAW, true>), grid, dim3(256), 0, ctx->stream, T->nodes, order, m, (uint32_t)ctx->i_begin,
+                           posm, vel, acc_out, ctx->cfg.G, ctx->cfg.eps2, ctx->cfg.theta,
+                           (unsigned long long*)T->walk_counters, T->err_flag);
+    else
+        hipLaunchKernelGGL((k_walk<LAW, false>), grid, dim3(256), 0, ctx->stream, T->nodes, order, m, (uint32_t)ctx->i_begin,
+                           posm, vel, acc_out, ctx->cfg.G, ctx->cfg.eps2, ctx->cfg.theta,
+                           (unsigned long long*)T->walk_counters, T->err_flag);
+}
+
+}  // namespace
+
+int nb_tree_create(nbody_ctx* ctx) {
+    Octree* T = new Octree;
+    ctx->tree = T;
+    T->n = ctx->n;
+    T->D = ctx->cfg.max_depth;
+    const uint64_t n = T->n;
+    T->rs_nb = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
+    T->pf_nb = (uint32_t)((n + 255) / 256);
+    for (int s = 0; s < 2; ++s) {
+        NB_HIP(ctx, hipMalloc(&T->keys[s], n * sizeof(uint64_t)));
+        NB_HIP(ctx, hipMalloc(&T->idx[s], n * sizeof(uint32_t)));
+    }
+    NB_HIP(ctx, hipMalloc(&T->lo, n));
+    NB_HIP(ctx, hipMalloc(&T->top, n));
+    NB_HIP(ctx, hipMalloc(&T->flags, n));
+    NB_HIP(ctx, hipMalloc(&T->body_node, n * sizeof(uint32_t)));
+    NB_HIP(ctx, hipMalloc(&T->rs_counts, (size_t)256 * T->rs_nb * sizeof(uint32_t)));
+    NB_HIP(ctx, hipMalloc(&T->row_total, 256 * sizeof(uint32_t)));
+    NB_HIP(ctx, hipMalloc(&T->row_base, 257 * sizeof(uint32_t)));
+    NB_HIP(ctx, hipMalloc(&T->blk, (size_t)NCNT * T->pf_nb * sizeof(uint32_t)));
+    NB_HIP(ctx, hipMalloc(&T->lvl_total, NCNT * sizeof(uint32_t)));
+    NB_HIP(ctx, hipMalloc(&T->lvl_start, (NCNT + 1) * sizeof(uint32_t)));
+    NB_HIP(ctx, hipMalloc(&T->walk_counters, 8 * sizeof(uint64_t)));
+    NB_HIP(ctx, hipMalloc(&T->err_flag, sizeof(uint32_t)));
+    NB_HIP(ctx, hipMemsetAsync(T->err_flag, 0, sizeof(uint32_t), ctx->stream));
+    if (ctx->i_count < ctx->n) NB_HIP(ctx, hipMalloc(&T->shard_order, ctx->i_count * sizeof(uint32_t)));
+    return ensure_nodes(ctx, T, 2 * n + 1024);
+}
+
+void nb_tree_destroy(nbody_ctx* ctx) {
+    Octree* T = ctx->tree;
+    if (!T) return;
+    for (int s = 0; s < 2; ++s) {
+        if (T->keys[s]) hipFree(T->keys[s]);
+        if (T->idx[s]) hipFree(T->idx[s]);
+    }
+    void* ptrs[] = {T->lo, T->top, T->flags, T->body_node, T->rs_counts, T->row_total, T->row_base, T->blk,
+                    T->lvl_total, T->lvl_start, T->nodes, T->bmin, T->bmax, T->export_buf, T->shard_order,
+                    T->walk_counters, T->err_flag};
+    for (void* p : ptrs)
+        if (p) hipFree(p);
+    delete T;
+    ctx->tree = nullptr;
+}
+
+int nb_tree_build(nbody_ctx* ctx, const float4* posm_in) {
+    Octree* T = ctx->tree;
+    const uint32_t n = (uint32_t)T->n;
+    const int D = (int)T->D;
+    hipStream_t st = ctx->stream;
+    hipLaunchKernelGGL(k_morton, dim3((n + 255) / 256), dim3(256), 0, st, posm_in, n, ctx->cfg.world, D, T->keys[0],
+                       T->idx[0]);
+    NB_HIP(ctx, hipGetLastError());
+    int cur = 0;
+    const int bits = 3 * D;
+    for (int shift = 0; shift < bits; shift += 8) {
+        hipLaunchKernelGGL(k_rs_hist, dim3(T->rs_nb), dim3(RS_THREADS), 0, st, T->keys[cur], n, shift, T->rs_counts, T->rs_nb);
+        hipLaunchKernelGGL(k_rowscan, dim3(256), dim3(256), 0, st, T->rs_counts, T->rs_nb, T->row_total);
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(256), 0, st, T->row_total, T->row_base, 256);
+        hipLaunchKernelGGL(k_rs_scatter, dim3(T->rs_nb), dim3(RS_THREADS), 0, st, T->keys[cur], T->idx[cur], T->keys[cur ^ 1],
+                           T->idx[cur ^ 1], n, shift, T->rs_counts, T->row_base, T->rs_nb);
+        NB_HIP(ctx, hipGetLastError());
+        cur ^= 1;
+    }
+    T->sorted = cur;
+    hipLaunchKernelGGL(k_prefix, dim3(T->pf_nb), dim3(256), 0, st, T->keys[cur], n, D, ctx->cfg.leaflist_mode, T->lo, T->top,
+                       T->flags, T->blk, T->pf_nb);
+    hipLaunchKernelGGL(k_rowscan, dim3(NCNT), dim3(256), 0, st, T->blk, T->pf_nb, T->lvl_total);
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(256), 0, st, T->lvl_total, T->lvl_start, NCNT);
+    NB_HIP(ctx, hipGetLastError());
+    NB_HIP(ctx, hipMemcpyAsync(T->h_lvl_start, T->lvl_start, sizeof T->h_lvl_start, hipMemcpyDeviceToHost, st));
+    NB_HIP(ctx, hipStreamSynchronize(st));
+    const uint64_t total = T->h_lvl_start[NCNT];
+    int r = ensure_nodes(ctx, T, total);
+    if (r) return r;
+    T->n_nodes = total;
+    NB_HIP(ctx, hipMemsetAsync(T->nodes, 0, total * sizeof(WNode), st));
+    hipLaunchKernelGGL(k_emit, dim3(T->pf_nb), dim3(256), 0, st, T->keys[cur], T->idx[cur], posm_in, n, D, T->lo, T->top,
+                       T->flags, T->blk, T->pf_nb, T->lvl_start, T->nodes, T->bmin, T->bmax, T->body_node,
+                       (uint32_t)T->cap_nodes, T->err_flag);
+    NB_HIP(ctx, hipGetLastError());
+    if (T->h_lvl_start[LIST_ROW + 1] > T->h_lvl_start[LIST_ROW] || T->h_lvl_start[D + 1] > T->h_lvl_start[D]) {
+        hipLaunchKernelGGL(k_leaflist, dim3((n + 255) / 256), dim3(256), 0, st, T->keys[cur], T->idx[cur], posm_in, n,
+                           ctx->cfg.leaflist_mode, T->flags, T->body_node, T->nodes, T->bmin, T->bmax,
+                           (uint32_t)T->cap_nodes, (uint32_t)D);
+        NB_HIP(ctx, hipGetLastError());
+    }
+    for (int d = D - 1; d >= 0; --d) {
+        const uint32_t first = T->h_lvl_start[d], count = T->h_lvl_start[d + 1] - first;
+        if (!count) continue;
+        hipLaunchKernelGGL(k_aggregate, dim3((count + 255) / 256), dim3(256), 0, st, T->nodes, T->bmin, T->bmax, first, count);
+    }
+    NB_HIP(ctx, hipGetLastError());
+    T->have_tree = true;
+    T->built = true;
+    ctx->counters.octree_nodes = total;
+    return NBODY_OK;
+}
+
+int nb_tree_walk(nbody_ctx* ctx, const float4* posm_in, const float4* vel_in, float4* acc_out) {
+    Octree* T = ctx->tree;
+    if (!T->have_tree) return nb_fail(ctx, NBODY_ERR_STATE, "no octree: call nbody_build_octree or nbody_upload_octree first");
+    hipStream_t st = ctx->stream;
+    const uint32_t m = (uint32_t)ctx->i_count;
+    const uint32_t* order = nullptr;
+    if (T->built) {
+        if (ctx->i_count == ctx->n) {
+            order = T->idx[T->sorted];
+        } else {
+            hipLaunchKernelGGL(k_compact_order, dim3(1), dim3(1024), 0, st, T->idx[T->sorted], (uint32_t)T->n,
+                               (uint32_t)ctx->i_begin, (uint32_t)(ctx->i_begin + ctx->i_count), T->shard_order);
+            order = T->shard_order;
+        }
+    }
+    if (ctx->counting) NB_HIP(ctx, hipMemsetAsync(T->walk_counters, 0, 8 * sizeof(uint64_t), st));
+    nb_time_begin(ctx, 1);
+    if (ctx->cfg.law == NBODY_LAW_WGSL_BIAS) launch_walk<NBODY_LAW_WGSL_BIAS>(ctx, T, order, m, posm_in, vel_in, acc_out);
+    else launch_walk<NBODY_LAW_PLUMMER>(ctx, T, order, m, posm_in, vel_in, acc_out);
+    nb_time_end(ctx, 1);
+    NB_HIP(ctx, hipGetLastError());
+    if (ctx->counting) {
+        uint64_t h[8];
+        NB_HIP(ctx, hipMemcpyAsync(h, T->walk_counters, sizeof h, hipMemcpyDeviceToHost, st));
+        NB_HIP(ctx, hipStreamSynchronize(st));
+        ctx->counters.bh_node_visits = h[0];
+        ctx->counters.bh_leaf_interactions = h[1];
+        ctx->counters.bh_aggregate_interactions = h[2];
+        ctx->counters.bh_wave_node_visits = h[3];
+        ctx->counters.bh_max_stack = h[4];
+        return check_err_flag(ctx, T, "traversal");
+    }
+    return NBODY_OK;
+}
+
+int nb_tree_download(nbody_ctx* ctx, nbody_octree_node* host_nodes, uint64_t cap, uint64_t* n_nodes) {
+    Octree* T = ctx->tree;
+    if (!T->have_tree) return nb_fail(ctx, NBODY_ERR_STATE, "no octree to download");
+    if (n_nodes) *n_nodes = T->n_nodes;
+    if (!host_nodes) return NBODY_OK;
+    if (cap < T->n_nodes) return nb_fail(ctx, NBODY_ERR_CAPACITY, "nbody_download_octree: host buffer too small");
+    void* dev = nullptr;
+    size_t bytes = 0;
+    int r = nb_tree_device_nodes(ctx, &dev, &bytes);
+    if (r) return r;
+    NB_HIP(ctx, hipMemcpyAsync(host_nodes, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return check_err_flag(ctx, T, "octree build");
+}
+
+int nb_tree_device_nodes(nbody_ctx* ctx, void** ptr, size_t* bytes) {
+    Octree* T = ctx->tree;
+    if (!T->have_tree) return nb_fail(ctx, NBODY_ERR_STATE, "no octree");
+    if (T->export_cap < T->n_nodes) {
+        if (T->export_buf) NB_HIP(ctx, hipFree(T->export_buf));
+        T->export_buf = nullptr;
+        T->export_cap = 0;
+        NB_HIP(ctx, hipMalloc(&T->export_buf, T->cap_nodes * sizeof(nbody_octree_node)));
+        T->export_cap = T->cap_nodes;
+    }
+    const uint32_t cnt = (uint32_t)T->n_nodes;
+    hipLaunchKernelGGL(k_export, dim3((cnt + 255) / 256), dim3(256), 0, ctx->stream, T->nodes, T->bmin, T->bmax, cnt,
+                       T->export_buf);
+    NB_HIP(ctx, hipGetLastError());
+    *ptr = T->export_buf;
+    if (bytes) *bytes = T->n_nodes * sizeof(nbody_octree_node);
+    return NBODY_OK;
+}
+
+int nb_tree_upload(nbody_ctx* ctx, const nbody_octree_node* host_nodes, uint64_t n_nodes) {
+    Octree* T = ctx->tree;
+    int r = ensure_nodes(ctx, T, n_nodes);
+    if (r) return r;
+    // validate child indices on the host: the traversal trusts them
+    for (uint64_t i = 0; i < n_nodes; ++i) {
+        const nbody_octree_node& nd = host_nodes[i];
+        if (nd.node_type > NBODY_NODE_INTERIOR) return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_upload_octree: bad node_type");
+        if (nd.node_type == NBODY_NODE_LEAFLIST) {
+            if ((uint64_t)nd.child_indices[0] + std::max<uint32_t>(nd.child_indices[1], 1u) > n_nodes)
+                return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_upload_octree: leaf list outside the node array");
+        } else if (nd.node_type == NBODY_NODE_INTERIOR) {
+            for (int k = 0; k < 8; ++k)
+                if (nd.child_indices[k] >= n_nodes) return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_upload_octree: child index outside the node array");
+        }
+    }
+    if (T->export_cap < n_nodes) {
+        if (T->export_buf) NB_HIP(ctx, hipFree(T->export_buf));
+        T->export_buf = nullptr;
+        T->export_cap = 0;
+        NB_HIP(ctx, hipMalloc(&T->export_buf, T->cap_nodes * sizeof(nbody_octree_node)));
+        T->export_cap = T->cap_nodes;
+    }
+    NB_HIP(ctx, hipMemcpyAsync(T->export_buf, host_nodes, n_nodes * sizeof(nbody_octree_node), hipMemcpyHostToDevice, ctx->stream));
+    const uint32_t cnt = (uint32_t)n_nodes;
+    hipLaunchKernelGGL(k_import, dim3((cnt + 255) / 256), dim3(256), 0, ctx->stream, T->export_buf, cnt, T->nodes, T->bmin, T->bmax);
+    NB_HIP(ctx, hipGetLastError());
+    NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    T->n_nodes = n_nodes;
+    T->have_tree = true;
+    T->built = false;  // no sorted order for this tree: targets are walked in index order
+    ctx->counters.octree_nodes = n_nodes;
+    return NBODY_OK;
+}
+
+int nb_tree_keys(nbody_ctx* ctx, uint64_t* keys, uint8_t* depth, uint32_t* order) {
+    Octree* T = ctx->tree;
+    if (!T->have_tree || !T->built) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_morton_keys needs a tree built by nbody_build_octree");
+    const uint64_t n = T->n;
+    std::vector<uint64_t> k(n);
+    std::vector<uint32_t> id(n);
+    std::vector<uint8_t> tp(n), fl(n);
+    NB_HIP(ctx, hipMemcpyAsync(k.data(), T->keys[T->sorted], n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    NB_HIP(ctx, hipMemcpyAsync(id.data(), T->idx[T->sorted], n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    NB_HIP(ctx, hipMemcpyAsync(tp.data(), T->top, n, hipMemcpyDeviceToHost, ctx->stream));
+    NB_HIP(ctx, hipMemcpyAsync(fl.data(), T->flags, n, hipMemcpyDeviceToHost, ctx->stream));
+    NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint64_t r = 0; r < n; ++r) {
+        const uint32_t b = id[r];
+        if (keys) keys[b] = k[r];
+        if (depth) depth[b] = (fl[r] & 4u) ? (uint8_t)T->D : tp[r];
+        if (order) order[r] = b;
+    }
+    return NBODY_OK;
+}

@@ -562,6 +562,58 @@ int orc_bh_accel(int law, int64_t n, const float* pos16, const float* vel16, con
     return err;
 }
 
+// The same traversal (identical f32 acceptance decisions, so the identical node sequence) with
+// every accepted term evaluated and summed in f64: the yardstick for the walk's rounding error.
+void orc_bh_accel_f64(int law, int64_t n, const float* pos16, const float* vel16, const Node96* nodes, double G,
+                      double eps2, float theta, int64_t i_begin, int64_t i_count, double* acc_out) {
+    (void)n;
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t i = i_begin; i < i_begin + i_count; ++i) {
+        V3 pos = ld16(pos16, i);
+        double p[3] = {pos.x, pos.y, pos.z};
+        double v[3] = {0, 0, 0};
+        if (vel16) {
+            v[0] = vel16[4 * i];
+            v[1] = vel16[4 * i + 1];
+            v[2] = vel16[4 * i + 2];
+        }
+        double a[3] = {0, 0, 0};
+        std::vector<uint32_t> stack;
+        stack.push_back(0);
+        while (!stack.empty()) {
+            uint32_t idx = stack.back();
+            stack.pop_back();
+            const Node96& node = nodes[idx];
+            bool take = node.node_type == T_LEAFBODY;
+            if (!take) {
+                float d = node.range;
+                float r = distance(pos, gcom(node));
+                take = (d / r) < theta;
+            }
+            if (take) {
+                double q[3] = {node.com[0], node.com[1], node.com[2]};
+                double t[3];
+                term_f64(law, p, v, q, node.total_mass, G, eps2, t);
+                a[0] += t[0];
+                a[1] += t[1];
+                a[2] += t[2];
+            } else if (node.node_type == T_LEAFLIST) {
+                uint32_t j = node.child[0], k = 0;
+                do {
+                    stack.push_back(j + k);
+                    ++k;
+                } while (k < node.child[1]);
+            } else {
+                for (unsigned k = 0; k < 8; ++k)
+                    if (node.child[k] != 0u) stack.push_back(node.child[k]);
+            }
+        }
+        acc_out[3 * (i - i_begin)] = a[0];
+        acc_out[3 * (i - i_begin) + 1] = a[1];
+        acc_out[3 * (i - i_begin) + 2] = a[2];
+    }
+}
+
 // src/nbody_gpu_bh.rs:445-527 -- nsteps of the Barnes-Hut binary: build from current positions,
 // walk, integrate with clamp, swap.  Returns 0 or a negative error of the stages above.
 int orc_step_bh(int law, int64_t n, int nsteps, const float* masses, float G, float eps2, float dt, float theta,

@@ -2,9 +2,10 @@
 same seeded inputs (src/nbody.wgsl and src/nbody_cpu.rs semantics).
 
 Tolerance (stated by the task): per-body accelerations within 1e-5 relative (||da||/||a||),
-FP32 with a different summation order.  Where the f32 oracle's own rounding error against the
-f64 evaluation of the same terms is larger than that (cancellation-dominated bodies), the GPU
-must be at least as close to f64 as the reference order is."""
+FP32 with a different summation order.  The f32 oracle is itself only known to its own rounding
+error e_ref against the f64 evaluation of the same terms (large for cancellation-dominated
+bodies and long sequential sums), so the distance to f64 is bounded by 1e-5*|a| + e_ref --
+the condition every result within 1e-5 of the reference satisfies."""
 import numpy as np
 import pytest
 
@@ -32,8 +33,7 @@ def check_acc(orc, law, m, pos, vel, acc_gpu):
     e_gpu = np.linalg.norm(acc_gpu[:, :3].astype(np.float64) - ref64, axis=1)
     e_ref = np.linalg.norm(ref32[:, :3].astype(np.float64) - ref64, axis=1)
     scale = np.linalg.norm(ref64, axis=1)
-    allowed = np.maximum(TOL * scale, e_ref) + 1e-30
-    bad = e_gpu > allowed
+    bad = e_gpu > TOL * scale + e_ref + 1e-30
     assert not bad.any(), f"{bad.sum()} of {n} bodies off: worst {np.max(e_gpu / scale):.3e} rel"
     return float(np.max(e_gpu / np.maximum(scale, 1e-300)))
 

@@ -350,6 +350,31 @@ void orc_accel_allpairs_f64(int law, int64_t n, const float* pos16, const float*
     }
 }
 
+// Sum over sources of the NORM of each term (f64): the scale of the rounding error any f32
+// evaluation of the sum carries (error <= c * eps_f32 * this), whatever the summation order.
+void orc_accel_allpairs_abs(int law, int64_t n, const float* pos16, const float* vel16, const float* masses,
+                            double G, double eps2, int64_t i_begin, int64_t i_count, double* abs_out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = i_begin; i < i_begin + i_count; ++i) {
+        double p[3] = {pos16[4 * i], pos16[4 * i + 1], pos16[4 * i + 2]};
+        double v[3] = {0, 0, 0};
+        if (vel16) {
+            v[0] = vel16[4 * i];
+            v[1] = vel16[4 * i + 1];
+            v[2] = vel16[4 * i + 2];
+        }
+        double a = 0;
+        for (int64_t j = 0; j < n; ++j) {
+            if (j == i) continue;
+            double q[3] = {pos16[4 * j], pos16[4 * j + 1], pos16[4 * j + 2]};
+            double t[3];
+            term_f64(law, p, v, q, masses[j], G, eps2, t);
+            a += std::sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
+        }
+        abs_out[i - i_begin] = a;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // src/nbody_cpu.rs:321-360 -- the CPU binary's step, literally: forces from set 1, Euler update
 // of set 2 (which is NOT derived from set 1: two interleaved states), then swap.

@@ -69,6 +69,17 @@ def accel_allpairs_f64(law, pos16, vel16, masses, G=0.0066743, eps2=1.0, i_begin
     return out
 
 
+def accel_allpairs_abs(law, pos16, vel16, masses, G=0.0066743, eps2=1.0, i_begin=0, i_count=None):
+    """Per body, the sum of the norms of its source terms (float64): the rounding-error scale."""
+    pos16, vel16, masses = _c(pos16), _c(vel16), _c(masses)
+    n = len(masses)
+    i_count = n - i_begin if i_count is None else i_count
+    out = np.zeros(i_count, np.float64)
+    lib().orc_accel_allpairs_abs(C.c_int(law), C.c_int64(n), _p(pos16), _p(vel16), _p(masses), C.c_double(float(np.float32(G))),
+                                 C.c_double(eps2), C.c_int64(i_begin), C.c_int64(i_count), _p(out))
+    return out
+
+
 def step_cpu(masses, p1, v1, a1, p2, v2, a2, nsteps):
     """src/nbody_cpu.rs:321-360, nsteps times.  Returns the six arrays after the steps; the first
     three are the set the next step would read."""
@@ -113,7 +124,9 @@ def build_octree(pos16, masses, variant=0, world=250.0, max_depth=16, leaflist_m
             continue
         if cnt < 0:
             raise RuntimeError(f"oracle octree build failed: {cnt}")
-        return nodes[:cnt].copy(), leaf, dep, md.value
+        # byte-wise copy: numpy does not promise to copy the padding bytes of a structured dtype
+        raw = nodes.view(np.uint8).reshape(-1, 96)[:cnt].copy()
+        return raw.view(NODE_DTYPE).reshape(-1), leaf, dep, md.value
 
 
 def morton_keys(pos16, world=250.0, levels=16):

@@ -1,0 +1,134 @@
+"""The multi-GPU path on CPU: world_size-2 (and 3, uneven) gloo processes run the sharded driver
+(nbody_amd.shard.ShardedSim) with a test-only backend that computes with the CPU oracle.  What is
+under test is the product's exchange logic: shard ranges, the per-step all-gather of the packed
+positions, and that sharded stepping reproduces unsharded stepping bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+class OracleShardBackend:
+    """Test stand-in for HipShardBackend: same interface, oracle arithmetic on host tensors."""
+
+    def __init__(self, n, begin, count, law):
+        from oracle import oracle as orc
+        self.orc, self.n, self.b, self.c, self.law = orc, n, begin, count, law
+        self.full = torch.zeros(n, 4)          # packed {x,y,z,m}: the buffer the ranks all-gather
+        self.vel = np.zeros((n, 4), np.float32)
+        self.acc = np.zeros((n, 4), np.float32)
+
+    def upload(self, masses, pos16, vel16=None):
+        self.m = np.asarray(masses, np.float32)
+        f = self.full.numpy()
+        f[:, :3] = pos16[:, :3]
+        f[:, 3] = self.m
+        if vel16 is not None:
+            self.vel[:] = vel16
+
+    def posm(self):
+        return self.full
+
+    def step(self, kind):
+        orc, b, c = self.orc, self.b, self.c
+        f = self.full.numpy()
+        pos = np.zeros((self.n, 4), np.float32)
+        pos[:, :3] = f[:, :3]
+        if kind == "bh":
+            nodes, _, _, _ = orc.build_octree(pos, self.m)          # replicated tree
+            a, _ = orc.bh_accel(self.law, pos, self.vel, nodes, i_begin=b, i_count=c)
+            clamp = 250.0
+        else:
+            a = orc.accel_allpairs(self.law, pos, self.vel, self.m, i_begin=b, i_count=c)
+            clamp = 0.0
+        s = slice(b, b + c)
+        po, vo, ao = orc.integrate_wgsl(pos[s], self.vel[s], self.acc[s], a[s], clamp_world=clamp)
+        f[s, :3] = po[:, :3]          # only the own range changes; the exchange brings the rest
+        self.vel[s], self.acc[s] = vo, ao
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n, law, kind, steps, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nbody_amd.shard import ShardedSim, shard_range
+        from oracle import oracle as orc
+        orc.set_num_threads(2)
+        m, pos = orc.gen_refcube(n, seed=8)
+        vel = np.zeros((n, 4), np.float32)
+        vel[:, :3] = 0.2 * (orc.gen_refcube(n, seed=9)[1][:, :3] / 125.0 - 1.0)
+        b, c = shard_range(n, rank, world)
+        be = OracleShardBackend(n, b, c, law)
+        be.upload(m, pos, vel)
+        sim = ShardedSim(be, n)
+        assert (sim.begin, sim.count) == (b, c)
+        (sim.step_bh if kind == "bh" else sim.step_allpairs)(steps)
+        np.save(os.path.join(out_dir, f"posm_{rank}.npy"), be.full.numpy())
+        np.save(os.path.join(out_dir, f"vel_{rank}.npy"), be.vel[b:b + c])
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(world, n, law, kind, steps, tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n, law, kind, steps, str(tmp_path)), nprocs=world, join=True)
+    from nbody_amd.shard import shard_range
+    full = [np.load(tmp_path / f"posm_{r}.npy") for r in range(world)]
+    vel = np.zeros((n, 4), np.float32)
+    for r in range(world):
+        b, c = shard_range(n, r, world)
+        vel[b:b + c] = np.load(tmp_path / f"vel_{r}.npy")
+    return full, vel
+
+
+def test_shard_ranges_partition():
+    from nbody_amd.shard import shard_range
+    for n, w in ((10, 3), (1 << 20, 8), (7, 8), (1000, 1)):
+        r = [shard_range(n, k, w) for k in range(w)]
+        assert r[0][0] == 0 and sum(c for _, c in r) == n
+        for (b0, c0), (b1, _) in zip(r, r[1:]):
+            assert b0 + c0 == b1
+        assert max(c for _, c in r) - min(c for _, c in r) <= 1
+
+
+@pytest.mark.parametrize("world,n", [(2, 512), (3, 301)])
+def test_sharded_allpairs_equals_unsharded(orc, tmp_path, world, n):
+    steps, law = 3, orc.LAW_WGSL_BIAS
+    full, vel = _run(world, n, law, "allpairs", steps, tmp_path)
+    m, pos = orc.gen_refcube(n, seed=8)
+    v0 = np.zeros((n, 4), np.float32)
+    v0[:, :3] = 0.2 * (orc.gen_refcube(n, seed=9)[1][:, :3] / 125.0 - 1.0)
+    rp, rv, ra = orc.step_wgsl_allpairs(law, m, pos, v0, np.zeros_like(pos), steps)
+    for f in full:                       # every rank ends with every body's position and mass
+        assert np.array_equal(f[:, :3], rp[:, :3]) and np.array_equal(f[:, 3], m)
+    assert np.array_equal(vel, rv)
+
+
+def test_sharded_bh_equals_unsharded(orc, tmp_path):
+    world, n, steps, law = 2, 400, 2, orc.LAW_PLUMMER
+    full, vel = _run(world, n, law, "bh", steps, tmp_path)
+    m, pos = orc.gen_refcube(n, seed=8)
+    v0 = np.zeros((n, 4), np.float32)
+    v0[:, :3] = 0.2 * (orc.gen_refcube(n, seed=9)[1][:, :3] / 125.0 - 1.0)
+    rp, rv, ra = orc.step_bh(law, m, pos, v0, np.zeros_like(pos), steps)
+    for f in full:
+        assert np.array_equal(f[:, :3], rp[:, :3])
+    assert np.array_equal(vel, rv)

@@ -1,11 +1,12 @@
 import sys; sys.path.insert(0,'/root/repo')
 import numpy as np, nbody_amd as nb
-from oracle import oracle as orc
-n=1000
-m,pos=nb.gen_refcube(n,seed=1)
-vel=np.zeros((n,4),np.float32); vel[:,:3]=0.3*(nb.gen_refcube(n,seed=2)[1][:,:3]/125.0-1.0)
-with nb.NBodySim(n, law=1) as sim:
-    sim.upload(m,pos,vel); sim.step_allpairs(1); p1,v1,a1=sim.download()
-rp,rv,ra=orc.integrate_wgsl(pos,vel,np.zeros_like(pos),a1)
-print(np.abs(rp-p1).max(), np.abs(rv-v1).max(), (rp!=p1).sum(), (rv!=v1).sum())
-i=np.argwhere(rp!=p1)[:3]; print(i, rp[i[:,0]], p1[i[:,0]], pos[i[:,0]], vel[i[:,0]])
+g=np.load('/root/repo/tests/golden/refcube_n4096_s1.npz')
+m,pos,vel=g['masses'],g['pos'],g['vel']; n=len(m)
+for name,law in (("cpu_r6",0),("wgsl_bias",1),("plummer",2)):
+    with nb.NBodySim(n, law=law) as sim:
+        sim.upload(m,pos,vel); acc=sim.accel_allpairs()
+    ref64=g[f"acc64_{name}"]; e=np.linalg.norm(acc[:,:3]-ref64,axis=1); e_ref=np.linalg.norm(g[f"acc_{name}"][:,:3]-ref64,axis=1)
+    s=np.linalg.norm(ref64,axis=1)
+    bad=e>1e-5*s+e_ref
+    print(name, bad.sum(), (e/s).max(), (e_ref/s).max(), np.median(e/s), np.median(e_ref/s))
+    i=np.argmax(e/s - e_ref/s); print(i, e[i]/s[i], e_ref[i]/s[i], acc[i], ref64[i], g[f"acc_{name}"][i])

@@ -128,7 +128,8 @@ def main():
                    "n_bodies": n, "law": args.law, "parallelism": f"target-shard x{args.gpus}"},
         "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
-                     "kernel": "k_allpairs_plummer_pk" if args.law == "plummer" else "k_allpairs",
+                     "kernel": ("k_ap_sym (one evaluation per unordered pair)" if (args.law == "plummer" and world == 1)
+                                else "k_allpairs_plummer_pk" if args.law == "plummer" else "k_allpairs"),
                      "kernel_ms": kernel_ms, "launches": launches, "flop_per_interaction": flop,
                      "note": "FP32 vector (VALU) roofline; the path uses no MFMA and streams 16 B per source"},
     }

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(BLOCK) void k_allpairs(const float4* __restrict__ p
 template <int IPT>
 __global__ __launch_bounds__(BLOCK) void k_allpairs_plummer_pk(const float4* __restrict__ posm,
                                                                 float4* __restrict__ acc_part, int n, int i_begin,
-                                                                int i_count, int j_chunk, float eps2) {
+                                                                int i_count, int j_chunk, float eps2, int diag) {
     static_assert(IPT % 2 == 0, "packed kernel needs an even number of targets per lane");
     constexpr int H = IPT / 2;
     __shared__ float4 tile[2][TJ];
@@ -154,8 +154,10 @@ __global__ __launch_bounds__(BLOCK) void k_allpairs_plummer_pk(const float4* __r
         py[k] = f2{p0.y, p1.y};
         pz[k] = f2{p0.z, p1.z};
     }
-    const int j0 = blockIdx.y * j_chunk;
-    const int j1 = min(n, j0 + j_chunk);
+    // diag: the sources are the workgroup's own BLOCK*IPT targets only (the within-superblock
+    // term of the symmetric path)
+    const int j0 = diag ? ib : blockIdx.y * j_chunk;
+    const int j1 = min(n, j0 + (diag ? BLOCK * IPT : j_chunk));
     const int ntiles = (j1 - j0 + TJ - 1) / TJ;
 
     f2 sx[H], sy[H], sz[H], cx[H], cy[H], cz[H];
@@ -320,7 +322,7 @@ template <int IPT>
 void launch_ap_pk(nbody_ctx* ctx, const float4* posm, int slices, int j_chunk) {
     dim3 grid((unsigned)((ctx->i_count + BLOCK * IPT - 1) / (BLOCK * IPT)), (unsigned)slices);
     hipLaunchKernelGGL((k_allpairs_plummer_pk<IPT>), grid, dim3(BLOCK), 0, ctx->stream, posm, ctx->acc_part, (int)ctx->n,
-                       (int)ctx->i_begin, (int)ctx->i_count, j_chunk, ctx->cfg.eps2);
+                       (int)ctx->i_begin, (int)ctx->i_count, j_chunk, ctx->cfg.eps2, 0);
 }
 
 template <int LAW>
@@ -374,9 +376,27 @@ int nb_time_collect(nbody_ctx* ctx, int which) {
     return NBODY_OK;
 }
 
+// Un-scaled PLUMMER sums of every body over the sources of its own 1024-body superblock.
+int nb_allpairs_diag(nbody_ctx* ctx, const float4* posm_in, float4* diag_out) {
+    dim3 grid((unsigned)((ctx->n + BLOCK * 4 - 1) / (BLOCK * 4)), 1);
+    hipLaunchKernelGGL((k_allpairs_plummer_pk<4>), grid, dim3(BLOCK), 0, ctx->stream, posm_in, diag_out, (int)ctx->n, 0,
+                       (int)ctx->n, 0, ctx->cfg.eps2, 1);
+    NB_HIP(ctx, hipGetLastError());
+    return NBODY_OK;
+}
+
 // Forces on this context's targets from all n sources in posm_in; acc_out[i] for i in the range.
 int nb_allpairs_forces(nbody_ctx* ctx, const float4* posm_in, const float4* vel_in, float4* acc_out) {
     const int law = ctx->cfg.law;
+    if (law == NBODY_LAW_PLUMMER && ctx->i_count == ctx->n && ctx->n >= 8192 && env_int("NBODY_AP_SYM", 1)) {
+        // one evaluation per unordered pair; needs (superblocks x n / 2) x 16 B of partial rows
+        const uint32_t seg = (uint32_t)std::max(16, env_int("NBODY_AP_SEG", 512));
+        size_t free_b = 0, total_b = 0;
+        const uint64_t need = nb_sym_scratch_bytes(ctx->n, seg);
+        const bool have = ctx->sym != nullptr;
+        if (have || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need < free_b / 2))
+            return nb_allpairs_forces_sym(ctx, posm_in, acc_out, seg);
+    }
     int ipt = env_int("NBODY_AP_IPT", 0);
     if (ipt != 1 && ipt != 2 && ipt != 4 && ipt != 8) {
         // enough target blocks to fill the chip, else fewer targets per lane

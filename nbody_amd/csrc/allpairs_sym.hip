@@ -1,0 +1,298 @@
+// All-pairs PLUMMER forces evaluated once per UNORDERED pair (Newton's third law).
+//
+// The plain kernel (allpairs.hip) spends 12 packed lane-ops + 1 v_rsq_f32 per ordered pair.  The
+// distance, r^2 and r^-3 of a pair serve both bodies; what differs is the mass factor and the sign.
+// Bodies are grouped in superblocks of 1024 (one workgroup: 4 wavefronts x 64 lanes x 4 targets
+// held in registers, two per packed register pair).  A work item is (superblock a, a run of
+// 64-body source tiles that lie in LATER superblocks).  Per source tile every lane meets each of
+// the 64 sources once: at step t lane l reads source (l + t) mod 64 from LDS (conflict-free),
+// updates its four targets' accelerations in registers, and adds the four reactions on that
+// source to the wavefront's own LDS accumulator by a plain read-add-write (lane-distinct
+// addresses, one wavefront per accumulator, LDS operations of a wavefront execute in order;
+// ds_add_f32 was measured an order of magnitude slower here).  After the tile the four wavefronts' accumulators are
+// summed in a fixed order and written as that item's partial row; a final kernel adds, per body
+// and in a fixed order, the partial rows of all earlier superblocks, the target-side partials of
+// its own superblock's items and the within-superblock term.  No atomics reach global memory, so
+// results are reproducible bit for bit.
+//
+// Per step (8 pair-interactions = 16 ordered interactions) a lane issues 32 v_pk_*_f32,
+// 4 v_rsq_f32 and 3 v_add_f32: about 21 cycles per ordered interaction against 34 for the plain
+// kernel.
+#include "ctx.h"
+#include <algorithm>
+#include <vector>
+
+namespace {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+constexpr int SB = 1024;       // bodies per superblock
+constexpr int TILE = 64;       // sources per tile
+constexpr int TILES_PER_SB = SB / TILE;
+
+struct SymItem {
+    uint32_t a;           // target superblock
+    uint32_t tile_begin;  // source tiles [tile_begin, tile_end)
+    uint32_t tile_end;
+    uint32_t pad;
+};
+
+// UNIFORM: every body has the same mass, which is then applied once per body by the reduction
+// instead of twice per pair here.
+template <bool UNIFORM>
+__global__ __launch_bounds__(256) void k_ap_sym(const float4* __restrict__ posm, int n, const SymItem* __restrict__ items,
+                                                const unsigned long long* __restrict__ rowoff,
+                                                float4* __restrict__ part_j, float4* __restrict__ part_i, float eps2) {
+    // sources are stored twice (entries k and k+64) so that lane + t never needs a modulo
+    __shared__ float4 tile[2][2 * TILE];
+    __shared__ float4 accj[3][4][2 * TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const SymItem it = items[blockIdx.x];
+    const int ibase = (int)it.a * SB + wave * 256 + lane;
+
+    f2 px[2], py[2], pz[2], pm[2], ax[2], ay[2], az[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int i0 = ibase + (2 * h) * 64, i1 = i0 + 64;
+        // padding bodies: zero mass and so far away that r^-3 underflows to exactly 0
+        const float4 far = make_float4(1e18f, 1e18f, 1e18f, 0.0f);
+        float4 p0 = posm[min(i0, n - 1)], p1 = posm[min(i1, n - 1)];
+        if (i0 >= n) p0 = far;
+        if (i1 >= n) p1 = far;
+        px[h] = f2{p0.x, p1.x};
+        py[h] = f2{p0.y, p1.y};
+        pz[h] = f2{p0.z, p1.z};
+        pm[h] = f2{-p0.w, -p1.w};  // negated: the reaction on a source is -m_i r^-3 d
+        ax[h] = ay[h] = az[h] = f2{0.0f, 0.0f};
+    }
+
+    auto load_tile = [&](uint32_t t) {
+        const int j = (int)t * TILE + lane;
+        float4 s = posm[min(j, n - 1)];
+        if (j >= n) s = make_float4(1e18f, 1e18f, 1e18f, 0.0f);  // padding source, as above
+        return s;
+    };
+    auto zero_acc = [&](int b) {
+#pragma unroll
+        for (int c = 0; c < 1; ++c) {
+            accj[b][wave][lane] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            accj[b][wave][lane + TILE] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+    };
+    auto flush = [&](uint32_t t, int b) {
+        // one wavefront sums the four accumulators (fixed order) and writes the tile's partial row
+        float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float4 u = accj[b][w][lane], v = accj[b][w][lane + TILE];
+            sx += u.x + v.x;
+            sy += u.y + v.y;
+            sz += u.z + v.z;
+        }
+        const unsigned long long row = rowoff[it.a] + ((unsigned long long)t - (unsigned long long)(it.a + 1) * TILES_PER_SB) * TILE;
+        part_j[row + lane] = make_float4(sx, sy, sz, 0.0f);
+    };
+
+    float4 pre = make_float4(0, 0, 0, 0);
+    if (wave == 0) pre = load_tile(it.tile_begin);
+    int tb = 0;  // tile buffer
+    int ab = 0;  // accumulator buffer (three deep: one being filled, one being flushed, one being zeroed)
+    for (uint32_t t = it.tile_begin; t < it.tile_end; ++t) {
+        if (wave == 0) {
+            tile[tb][lane] = pre;
+            tile[tb][lane + TILE] = pre;
+        }
+        zero_acc(ab);
+        __syncthreads();
+        if (wave == 0 && t + 1 < it.tile_end) pre = load_tile(t + 1);
+        if (t > it.tile_begin && wave == (int)((t - 1) & 3u)) flush(t - 1, (ab + 2) % 3);
+
+        const float4* tp = &tile[tb][lane];
+        float4* ap = &accj[ab][wave][lane];
+        float4 nxt = tp[0];
+#pragma unroll 8
+        for (int s = 0; s < TILE; ++s) {
+            const float4 src = nxt;
+            nxt = tp[s + 1];  // read ahead of this step's fence (entry lane+64 exists: the tile is stored twice)
+            f2 cx, cy, cz;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f2 dx = src.x - px[h], dy = src.y - py[h], dz = src.z - pz[h];
+                const f2 r2 = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dz, dz, (f2)eps2)));
+                f2 rinv;
+                rinv.x = __builtin_amdgcn_rsqf(r2.x);
+                rinv.y = __builtin_amdgcn_rsqf(r2.y);
+                const f2 r3 = (rinv * rinv) * rinv;
+                const f2 si = UNIFORM ? r3 : src.w * r3;   // on the targets: m_j r^-3 d
+                const f2 sj = UNIFORM ? -r3 : pm[h] * r3;  // on the source: -m_i r^-3 d
+                ax[h] = __builtin_elementwise_fma(si, dx, ax[h]);
+                ay[h] = __builtin_elementwise_fma(si, dy, ay[h]);
+                az[h] = __builtin_elementwise_fma(si, dz, az[h]);
+                if (h == 0) {
+                    cx = sj * dx;
+                    cy = sj * dy;
+                    cz = sj * dz;
+                } else {
+                    cx = __builtin_elementwise_fma(sj, dx, cx);
+                    cy = __builtin_elementwise_fma(sj, dy, cy);
+                    cz = __builtin_elementwise_fma(sj, dz, cz);
+                }
+            }
+            float4 aj = ap[s];
+            aj.x += cx.x + cx.y;
+            aj.y += cy.x + cy.y;
+            aj.z += cz.x + cz.y;
+            ap[s] = aj;
+            // the entry this lane reads at step s+1 is the one its neighbour has just written:
+            // keep the wavefront's LDS accesses in program order across steps
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        tb ^= 1;
+        ab = (ab + 1) % 3;
+    }
+    __syncthreads();
+    if (it.tile_end > it.tile_begin && wave == (int)((it.tile_end - 1) & 3u)) flush(it.tile_end - 1, (ab + 2) % 3);
+
+    float4* pi = part_i + (size_t)blockIdx.x * SB + wave * 256 + lane;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        pi[(2 * h) * 64] = make_float4(ax[h].x, ay[h].x, az[h].x, 0.0f);
+        pi[(2 * h + 1) * 64] = make_float4(ax[h].y, ay[h].y, az[h].y, 0.0f);
+    }
+}
+
+// acc_out[j] = G * ( diag[j] + sum over earlier superblocks a of part_j[a][j]
+//                             + sum over the items of j's superblock of part_i[item][j] ), in f64.
+__global__ void k_ap_sym_reduce(const float4* __restrict__ diag, const float4* __restrict__ part_j,
+                                const float4* __restrict__ part_i, const unsigned long long* __restrict__ rowoff,
+                                const uint32_t* __restrict__ item_start, int n, float G, float pair_scale,
+                                float4* __restrict__ acc_out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int b = j / SB;
+    double x = 0.0, y = 0.0, z = 0.0;
+    for (int a = 0; a < b; ++a) {
+        const float4 p = part_j[rowoff[a] + (unsigned long long)(j - (a + 1) * SB)];
+        x += p.x;
+        y += p.y;
+        z += p.z;
+    }
+    const uint32_t i0 = item_start[b], i1 = item_start[b + 1];
+    for (uint32_t i = i0; i < i1; ++i) {
+        const float4 p = part_i[(size_t)i * SB + (j - b * SB)];
+        x += p.x;
+        y += p.y;
+        z += p.z;
+    }
+    // pair_scale: the common mass when the pair kernel left the masses out; the within-superblock
+    // term always carries its masses
+    const float4 d = diag[j];
+    x = x * (double)pair_scale + d.x;
+    y = y * (double)pair_scale + d.y;
+    z = z * (double)pair_scale + d.z;
+    acc_out[j] = make_float4(G * (float)x, G * (float)y, G * (float)z, 0.0f);
+}
+
+}  // namespace
+
+struct SymPlan {
+    uint64_t n = 0;
+    uint32_t n_items = 0;
+    SymItem* items = nullptr;
+    unsigned long long* rowoff = nullptr;
+    uint32_t* item_start = nullptr;
+    float4* part_j = nullptr;
+    float4* part_i = nullptr;
+    float4* diag = nullptr;
+};
+
+void nb_sym_destroy(nbody_ctx* ctx) {
+    SymPlan* P = ctx->sym;
+    if (!P) return;
+    void* ptrs[] = {P->items, P->rowoff, P->item_start, P->part_j, P->part_i, P->diag};
+    for (void* p : ptrs)
+        if (p) hipFree(p);
+    delete P;
+    ctx->sym = nullptr;
+}
+
+// Bytes of scratch the symmetric path needs for n bodies (0 if it does not apply).
+uint64_t nb_sym_scratch_bytes(uint64_t n, uint32_t seg_tiles) {
+    const uint64_t nsb = (n + SB - 1) / SB, nt = (n + TILE - 1) / TILE;
+    if (nsb < 2) return 0;
+    uint64_t rows = 0, items = 0;
+    for (uint64_t a = 0; a + 1 < nsb; ++a) {
+        const uint64_t tiles = nt - (a + 1) * TILES_PER_SB;
+        rows += tiles * TILE;
+        items += (tiles + seg_tiles - 1) / seg_tiles;
+    }
+    return (rows + items * SB + n) * sizeof(float4);
+}
+
+static int sym_prepare(nbody_ctx* ctx, uint32_t seg_tiles) {
+    if (ctx->sym && ctx->sym->n == ctx->n) return NBODY_OK;
+    nb_sym_destroy(ctx);
+    SymPlan* P = new SymPlan;
+    ctx->sym = P;
+    P->n = ctx->n;
+    const uint64_t n = ctx->n;
+    const uint32_t nsb = (uint32_t)((n + SB - 1) / SB), nt = (uint32_t)((n + TILE - 1) / TILE);
+    std::vector<SymItem> items;
+    std::vector<unsigned long long> rowoff(nsb + 1, 0);
+    std::vector<uint32_t> item_start(nsb + 1, 0);
+    unsigned long long rows = 0;
+    for (uint32_t a = 0; a < nsb; ++a) {
+        rowoff[a] = rows;
+        item_start[a] = (uint32_t)items.size();
+        const uint32_t first = (a + 1) * TILES_PER_SB;
+        if (first < nt) {
+            for (uint32_t t = first; t < nt; t += seg_tiles) items.push_back(SymItem{a, t, std::min(nt, t + seg_tiles), 0});
+            rows += (unsigned long long)(nt - first) * TILE;
+        }
+    }
+    rowoff[nsb] = rows;
+    item_start[nsb] = (uint32_t)items.size();
+    P->n_items = (uint32_t)items.size();
+    NB_HIP(ctx, hipMalloc(&P->items, std::max<size_t>(1, items.size()) * sizeof(SymItem)));
+    NB_HIP(ctx, hipMalloc(&P->rowoff, rowoff.size() * sizeof(unsigned long long)));
+    NB_HIP(ctx, hipMalloc(&P->item_start, item_start.size() * sizeof(uint32_t)));
+    NB_HIP(ctx, hipMalloc(&P->part_j, std::max<unsigned long long>(1, rows) * sizeof(float4)));
+    NB_HIP(ctx, hipMalloc(&P->part_i, std::max<size_t>(1, items.size()) * SB * sizeof(float4)));
+    NB_HIP(ctx, hipMalloc(&P->diag, n * sizeof(float4)));
+    NB_HIP(ctx, hipMemcpyAsync(P->items, items.data(), items.size() * sizeof(SymItem), hipMemcpyHostToDevice, ctx->stream));
+    NB_HIP(ctx, hipMemcpyAsync(P->rowoff, rowoff.data(), rowoff.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, ctx->stream));
+    NB_HIP(ctx, hipMemcpyAsync(P->item_start, item_start.data(), item_start.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    NB_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the host vectors go out of scope
+    return NBODY_OK;
+}
+
+int nb_allpairs_diag(nbody_ctx* ctx, const float4* posm_in, float4* diag_out);
+
+// PLUMMER forces on all n bodies of an unsharded context.
+int nb_allpairs_forces_sym(nbody_ctx* ctx, const float4* posm_in, float4* acc_out, uint32_t seg_tiles) {
+    int r = sym_prepare(ctx, seg_tiles);
+    if (r) return r;
+    SymPlan* P = ctx->sym;
+    const int n = (int)ctx->n;
+    nb_time_begin(ctx, 0);
+    const bool uniform = ctx->uniform_mass;
+    if (P->n_items) {
+        if (uniform)
+            hipLaunchKernelGGL(k_ap_sym<true>, dim3(P->n_items), dim3(256), 0, ctx->stream, posm_in, n, P->items, P->rowoff,
+                               P->part_j, P->part_i, ctx->cfg.eps2);
+        else
+            hipLaunchKernelGGL(k_ap_sym<false>, dim3(P->n_items), dim3(256), 0, ctx->stream, posm_in, n, P->items, P->rowoff,
+                               P->part_j, P->part_i, ctx->cfg.eps2);
+    }
+    nb_time_end(ctx, 0);
+    NB_HIP(ctx, hipGetLastError());
+    r = nb_allpairs_diag(ctx, posm_in, P->diag);
+    if (r) return r;
+    hipLaunchKernelGGL(k_ap_sym_reduce, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, P->diag, P->part_j, P->part_i,
+                       P->rowoff, P->item_start, n, ctx->cfg.G, uniform ? ctx->mass0 : 1.0f, acc_out);
+    NB_HIP(ctx, hipGetLastError());
+    ctx->counters.interactions_allpairs += ctx->n * ctx->n;
+    return NBODY_OK;
+}

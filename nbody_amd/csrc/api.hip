@@ -188,6 +188,7 @@ void nbody_destroy(nbody_ctx* ctx) {
     nb_time_collect(ctx, 0);
     nb_time_collect(ctx, 1);
     nb_tree_destroy(ctx);
+    nb_sym_destroy(ctx);
     for (int s = 0; s < 2; ++s) {
         if (ctx->posm[s]) hipFree(ctx->posm[s]);
         if (ctx->vel[s]) hipFree(ctx->vel[s]);
@@ -208,6 +209,9 @@ int nbody_upload(nbody_ctx* ctx, const float* host_masses, const float* host_pos
     int r = set_device(ctx);
     if (r) return r;
     ctx->cur = 0;
+    ctx->mass0 = host_masses[0];
+    ctx->uniform_mass = true;
+    for (uint64_t i = 1; i < ctx->n && ctx->uniform_mass; ++i) ctx->uniform_mass = host_masses[i] == ctx->mass0;
     r = upload_set(ctx, 0, host_masses, host_pos16, host_vel16, host_acc16, true);
     if (r) return r;
     // second set: zeros (src/nbody_cpu.rs:58-60), mass kept in the pad lane

@@ -19,6 +19,8 @@ struct nbody_ctx {
     uint64_t i_begin = 0;  // this context's targets
     uint64_t i_count = 0;
     bool uploaded = false;
+    bool uniform_mass = false;  // every body has mass mass0 (checked at upload)
+    float mass0 = 0.0f;
 
     // Body state in HBM.  Two sets (the reference's bind groups A and B, src/nbody_gpu.rs:145-288);
     // `cur` is the set the next step reads.  posm[s][i] = {x, y, z, mass_i}.
@@ -35,6 +37,8 @@ struct nbody_ctx {
 
     // Octree state (octree.hip)
     struct Octree* tree = nullptr;
+    // symmetric all-pairs plan and scratch (allpairs_sym.hip)
+    struct SymPlan* sym = nullptr;
 
     // energy scratch
     double* energy_dev = nullptr;
@@ -75,6 +79,12 @@ int nb_energy(nbody_ctx* ctx, double* kinetic, double* potential);
 void nb_time_begin(nbody_ctx* ctx, int which);
 void nb_time_end(nbody_ctx* ctx, int which);
 int nb_time_collect(nbody_ctx* ctx, int which);
+
+// symmetric all-pairs (allpairs_sym.hip)
+int nb_allpairs_forces_sym(nbody_ctx* ctx, const float4* posm_in, float4* acc_out, uint32_t seg_tiles);
+uint64_t nb_sym_scratch_bytes(uint64_t n, uint32_t seg_tiles);
+void nb_sym_destroy(nbody_ctx* ctx);
+int nb_allpairs_diag(nbody_ctx* ctx, const float4* posm_in, float4* diag_out);
 
 // octree (octree.hip)
 int nb_tree_create(nbody_ctx* ctx);

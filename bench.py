@@ -105,8 +105,9 @@ def main():
     dt, kernel_ms, launches = timed_run(law, args.steps, args.warmup)
     interactions = float(n) * n * args.steps
     flop = FLOP_PER_INTERACTION[args.law]
-    # the dominant kernel: one launch evaluates count x n interactions on this rank
-    per_launch = float(count) * n
+    # the dominant kernel: one launch covers this rank's share of the N x N interactions (its
+    # targets x all sources, or its 1/world share of the pair tiles)
+    per_launch = float(n) * n / world
     achieved = per_launch * flop / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
     out = {
         "metric": "all-pairs body-body interactions/s at N=1M",
@@ -123,15 +124,17 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"all-pairs direct sum, N={n} Plummer sphere (a=12.5, equal masses, seed 42), "
-                               f"law={args.law}, velocity-Verlet dt=0.1, targets sharded over {args.gpus} GPU(s), "
-                               "per-step all-gather of positions",
+                               f"law={args.law}, velocity-Verlet dt=0.1, {args.gpus} GPU(s): pair tiles dealt over the "
+                               "ranks, per-step all-reduce of partial accelerations + all-gather of positions",
                    "n_bodies": n, "law": args.law, "parallelism": f"target-shard x{args.gpus}"},
         "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
-                     "kernel": ("k_ap_sym (one evaluation per unordered pair)" if (args.law == "plummer" and world == 1)
-                                else "k_allpairs_plummer_pk" if args.law == "plummer" else "k_allpairs"),
+                     "kernel": ("k_ap_sym" if (args.law == "plummer" and n >= 65536) else
+                                "k_allpairs_plummer_pk" if args.law == "plummer" else "k_allpairs"),
                      "kernel_ms": kernel_ms, "launches": launches, "flop_per_interaction": flop,
-                     "note": "FP32 vector (VALU) roofline; the path uses no MFMA and streams 16 B per source"},
+                     "note": "FP32 vector (VALU) roofline, algorithmic 20 flop per ordered interaction x N^2. k_ap_sym "
+                             "evaluates each unordered pair once (Newton's third law), so it executes about half of "
+                             "those flops; the plain kernel (one evaluation per ordered pair) reaches 0.57 of peak"},
     }
     if not args.no_extras and args.law == "plummer":
         # the reference's shader law (src/nbody.wgsl:54-81) on the same bodies, fewer steps

@@ -102,7 +102,8 @@ enum nbody_buffer {
     NBODY_BUF_POSM = 0,  /* current positions, f32[N][4]; the pad lane carries the body's mass */
     NBODY_BUF_VEL = 1,   /* current velocities f32[N][4] */
     NBODY_BUF_ACC = 2,   /* current accelerations f32[N][4] */
-    NBODY_BUF_OCTREE = 3 /* nbody_octree_node[n_nodes] after nbody_export_octree */
+    NBODY_BUF_OCTREE = 3, /* nbody_octree_node[n_nodes], exported on request */
+    NBODY_BUF_ACC_PARTIAL = 4 /* f32[N][4] written by nbody_allpairs_partial, read by nbody_integrate_partial */
 };
 
 /* Work done since nbody_create or the last nbody_counters_reset; for roofline arithmetic. */
@@ -146,6 +147,15 @@ int nbody_step_allpairs(nbody_ctx* ctx, int nsteps);
  * traversal, integration with clamp to [0,world]^3, swap. */
 int nbody_step_bh(nbody_ctx* ctx, int nsteps);
 
+/* Multi-GPU all-pairs with ONE evaluation per unordered pair (PLUMMER law, Verlet).  The pair
+ * tiles of all N bodies are dealt out over nparts parts (one per GPU): part `part` writes its
+ * contribution to EVERY body's acceleration into NBODY_BUF_ACC_PARTIAL.  The host sums that
+ * buffer over the parts (RCCL all-reduce), then nbody_integrate_partial advances this context's
+ * own targets with the summed accelerations and swaps the sets; the host then all-gathers
+ * NBODY_BUF_POSM as after nbody_step_allpairs.  No counterpart in the reference (single device). */
+int nbody_allpairs_partial(nbody_ctx* ctx, uint32_t part, uint32_t nparts);
+int nbody_integrate_partial(nbody_ctx* ctx);
+
 /* Forces only (no integration, no swap), for parity checks against src/nbody.wgsl:50-116 and
  * src/nbodybh.wgsl:63-161.  host_acc16_out is f32[N][4]; only this context's targets are written. */
 int nbody_accel_allpairs(nbody_ctx* ctx, float* host_acc16_out);
@@ -182,6 +192,8 @@ int nbody_set_counting(nbody_ctx* ctx, int on);
  * that exchange shards themselves (RCCL all-gather of NBODY_BUF_POSM).  No counterpart in the
  * reference (it is single-device). */
 int nbody_device_buffer(nbody_ctx* ctx, int which, void** dev_ptr, size_t* bytes);
+/* Copies the first `bytes` bytes of one of those buffers to the host (blocks). */
+int nbody_read_buffer(nbody_ctx* ctx, int which, void* host_dst, size_t bytes);
 /* The hipStream_t the context enqueues on. */
 void* nbody_stream(nbody_ctx* ctx);
 /* Average duration in milliseconds of the dominant kernel (all-pairs force kernel, or the

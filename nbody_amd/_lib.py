@@ -59,6 +59,8 @@ SYMBOLS = {
     "nbody_upload_alt": (C.c_int, [_P, _P, _P, _P]),
     "nbody_step_allpairs": (C.c_int, [_P, C.c_int]),
     "nbody_step_bh": (C.c_int, [_P, C.c_int]),
+    "nbody_allpairs_partial": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    "nbody_integrate_partial": (C.c_int, [_P]),
     "nbody_accel_allpairs": (C.c_int, [_P, _P]),
     "nbody_accel_bh": (C.c_int, [_P, _P]),
     "nbody_build_octree": (C.c_int, [_P]),
@@ -73,6 +75,7 @@ SYMBOLS = {
     "nbody_counters_reset": (C.c_int, [_P]),
     "nbody_set_counting": (C.c_int, [_P, C.c_int]),
     "nbody_device_buffer": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "nbody_read_buffer": (C.c_int, [_P, C.c_int, _P, C.c_size_t]),
     "nbody_stream": (_P, [_P]),
     "nbody_kernel_time": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "nbody_set_kernel_timing": (C.c_int, [_P, C.c_int]),

@@ -376,32 +376,53 @@ int nb_time_collect(nbody_ctx* ctx, int which) {
     return NBODY_OK;
 }
 
-// Un-scaled PLUMMER sums of every body over the sources of its own 1024-body superblock.
-int nb_allpairs_diag(nbody_ctx* ctx, const float4* posm_in, float4* diag_out) {
-    dim3 grid((unsigned)((ctx->n + BLOCK * 4 - 1) / (BLOCK * 4)), 1);
-    hipLaunchKernelGGL((k_allpairs_plummer_pk<4>), grid, dim3(BLOCK), 0, ctx->stream, posm_in, diag_out, (int)ctx->n, 0,
-                       (int)ctx->n, 0, ctx->cfg.eps2, 1);
+// Un-scaled PLUMMER sums of every body over the sources of its own superblock (256 * tpl bodies).
+int nb_allpairs_diag(nbody_ctx* ctx, const float4* posm_in, float4* diag_out, int tpl) {
+    dim3 grid((unsigned)((ctx->n + BLOCK * tpl - 1) / (BLOCK * tpl)), 1);
+    if (tpl == 8)
+        hipLaunchKernelGGL((k_allpairs_plummer_pk<8>), grid, dim3(BLOCK), 0, ctx->stream, posm_in, diag_out, (int)ctx->n, 0,
+                           (int)ctx->n, 0, ctx->cfg.eps2, 1);
+    else
+        hipLaunchKernelGGL((k_allpairs_plummer_pk<4>), grid, dim3(BLOCK), 0, ctx->stream, posm_in, diag_out, (int)ctx->n, 0,
+                           (int)ctx->n, 0, ctx->cfg.eps2, 1);
     NB_HIP(ctx, hipGetLastError());
     return NBODY_OK;
+}
+
+// One part's share of the pair tiles of ALL bodies (PLUMMER): acc_tmp[j] for every j.
+int nb_allpairs_partial(nbody_ctx* ctx, uint32_t part, uint32_t nparts) {
+    const int tpl = env_int("NBODY_AP_SYM_TPL", 8) == 4 ? 4 : 8;
+    const uint64_t nsb = (ctx->n + 256 * tpl - 1) / (256 * tpl), nt = (ctx->n + 63) / 64;
+    uint32_t seg = (uint32_t)std::min<uint64_t>(512, std::max<uint64_t>(4, nsb * nt / 2 / 32768));
+    if (env_int("NBODY_AP_SEG", 0) > 0) seg = (uint32_t)env_int("NBODY_AP_SEG", 0);
+    return nb_allpairs_forces_sym(ctx, ctx->posm[ctx->cur], ctx->acc_tmp, seg, tpl, part, nparts);
 }
 
 // Forces on this context's targets from all n sources in posm_in; acc_out[i] for i in the range.
 int nb_allpairs_forces(nbody_ctx* ctx, const float4* posm_in, const float4* vel_in, float4* acc_out) {
     const int law = ctx->cfg.law;
-    if (law == NBODY_LAW_PLUMMER && ctx->i_count == ctx->n && ctx->n >= 8192 && env_int("NBODY_AP_SYM", 1)) {
+    // NBODY_AP_SYM: 0 never, 1 whenever there are two superblocks; unset: from N = 65,536 up, where
+    // the pair kernel's partial rows and their reduction no longer outweigh what it saves
+    const int sym_env = env_int("NBODY_AP_SYM", -1);
+    if (law == NBODY_LAW_PLUMMER && ctx->i_count == ctx->n && sym_env != 0 &&
+        ctx->n >= (sym_env == 1 ? 4097u : 65536u)) {
         // one evaluation per unordered pair; needs (superblocks x n / 2) x 16 B of partial rows
-        const uint32_t seg = (uint32_t)std::max(16, env_int("NBODY_AP_SEG", 512));
+        const int tpl = env_int("NBODY_AP_SYM_TPL", 8) == 4 ? 4 : 8;
+        // work items of `seg` source tiles each: aim at ~32K items (measured best at N = 1M)
+        const uint64_t nsb = (ctx->n + 256 * tpl - 1) / (256 * tpl), nt = (ctx->n + 63) / 64;
+        uint32_t seg = (uint32_t)std::min<uint64_t>(512, std::max<uint64_t>(4, nsb * nt / 2 / 32768));
+        if (env_int("NBODY_AP_SEG", 0) > 0) seg = (uint32_t)env_int("NBODY_AP_SEG", 0);
         size_t free_b = 0, total_b = 0;
-        const uint64_t need = nb_sym_scratch_bytes(ctx->n, seg);
+        const uint64_t need = nb_sym_scratch_bytes(ctx->n, seg, 256u * tpl);
         const bool have = ctx->sym != nullptr;
         if (have || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need < free_b / 2))
-            return nb_allpairs_forces_sym(ctx, posm_in, acc_out, seg);
+            return nb_allpairs_forces_sym(ctx, posm_in, acc_out, seg, tpl, 0, 1);
     }
     int ipt = env_int("NBODY_AP_IPT", 0);
     if (ipt != 1 && ipt != 2 && ipt != 4 && ipt != 8) {
-        // enough target blocks to fill the chip, else fewer targets per lane
-        ipt = 4;
-        while (ipt > 1 && ctx->i_count / (uint64_t)(BLOCK * ipt) < (uint64_t)ctx->num_cus) ipt >>= 1;
+        // four targets per lane measured best down to N = 65,536 (source slices fill the chip);
+        // fewer only when there are not even that many targets
+        ipt = ctx->i_count >= 16384 ? 4 : ctx->i_count >= 4096 ? 2 : 1;
     }
     const uint64_t tblocks = (ctx->i_count + BLOCK * ipt - 1) / (BLOCK * ipt);
     int slices = env_int("NBODY_AP_SLICES", 0);

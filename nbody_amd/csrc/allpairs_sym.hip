@@ -26,9 +26,7 @@ namespace {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-constexpr int SB = 1024;       // bodies per superblock
-constexpr int TILE = 64;       // sources per tile
-constexpr int TILES_PER_SB = SB / TILE;
+constexpr int TILE = 64;  // sources per tile
 
 struct SymItem {
     uint32_t a;           // target superblock
@@ -39,20 +37,26 @@ struct SymItem {
 
 // UNIFORM: every body has the same mass, which is then applied once per body by the reduction
 // instead of twice per pair here.
-template <bool UNIFORM>
+// P: targets per lane (superblock = 256 * P bodies), two per packed register pair.
+template <bool UNIFORM, int P>
 __global__ __launch_bounds__(256) void k_ap_sym(const float4* __restrict__ posm, int n, const SymItem* __restrict__ items,
                                                 const unsigned long long* __restrict__ rowoff,
-                                                float4* __restrict__ part_j, float4* __restrict__ part_i, float eps2) {
+                                                float4* __restrict__ part_j, float4* __restrict__ part_i, float eps2,
+                                                uint32_t part, uint32_t nparts, uint32_t n_items) {
     // sources are stored twice (entries k and k+64) so that lane + t never needs a modulo
     __shared__ float4 tile[2][2 * TILE];
     __shared__ float4 accj[3][4][2 * TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const SymItem it = items[blockIdx.x];
-    const int ibase = (int)it.a * SB + wave * 256 + lane;
+    constexpr int SB = 256 * P, TILES_PER_SB = SB / TILE, H = P / 2;
+    // with nparts > 1 (one part per GPU) this launch takes every nparts-th work item
+    const uint32_t item_id = blockIdx.x * nparts + part;
+    if (item_id >= n_items) return;
+    const SymItem it = items[item_id];
+    const int ibase = (int)it.a * SB + wave * (64 * P) + lane;
 
-    f2 px[2], py[2], pz[2], pm[2], ax[2], ay[2], az[2];
+    f2 px[H], py[H], pz[H], pm[H], ax[H], ay[H], az[H];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < H; ++h) {
         const int i0 = ibase + (2 * h) * 64, i1 = i0 + 64;
         // padding bodies: zero mass and so far away that r^-3 underflows to exactly 0
         const float4 far = make_float4(1e18f, 1e18f, 1e18f, 0.0f);
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(256) void k_ap_sym(const float4* __restrict__ posm,
             nxt = tp[s + 1];  // read ahead of this step's fence (entry lane+64 exists: the tile is stored twice)
             f2 cx, cy, cz;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < H; ++h) {
                 const f2 dx = src.x - px[h], dy = src.y - py[h], dz = src.z - pz[h];
                 const f2 r2 = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dz, dz, (f2)eps2)));
                 f2 rinv;
@@ -155,9 +159,9 @@ __global__ __launch_bounds__(256) void k_ap_sym(const float4* __restrict__ posm,
     __syncthreads();
     if (it.tile_end > it.tile_begin && wave == (int)((it.tile_end - 1) & 3u)) flush(it.tile_end - 1, (ab + 2) % 3);
 
-    float4* pi = part_i + (size_t)blockIdx.x * SB + wave * 256 + lane;
+    float4* pi = part_i + (size_t)item_id * SB + wave * (64 * P) + lane;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < H; ++h) {
         pi[(2 * h) * 64] = make_float4(ax[h].x, ay[h].x, az[h].x, 0.0f);
         pi[(2 * h + 1) * 64] = make_float4(ax[h].y, ay[h].y, az[h].y, 0.0f);
     }
@@ -167,13 +171,17 @@ __global__ __launch_bounds__(256) void k_ap_sym(const float4* __restrict__ posm,
 //                             + sum over the items of j's superblock of part_i[item][j] ), in f64.
 __global__ void k_ap_sym_reduce(const float4* __restrict__ diag, const float4* __restrict__ part_j,
                                 const float4* __restrict__ part_i, const unsigned long long* __restrict__ rowoff,
-                                const uint32_t* __restrict__ item_start, int n, float G, float pair_scale,
+                                const uint32_t* __restrict__ item_start, int n, int SB, uint32_t seg, float G,
+                                float pair_scale, uint32_t part, uint32_t nparts, int own_begin, int own_end,
                                 float4* __restrict__ acc_out) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const int b = j / SB;
     double x = 0.0, y = 0.0, z = 0.0;
     for (int a = 0; a < b; ++a) {
+        // the work item that covered (a, j's tile); with nparts > 1 only this part's items count
+        const uint32_t item = item_start[a] + (uint32_t)((j - (a + 1) * SB) / TILE) / seg;
+        if (item % nparts != part) continue;
         const float4 p = part_j[rowoff[a] + (unsigned long long)(j - (a + 1) * SB)];
         x += p.x;
         y += p.y;
@@ -181,6 +189,7 @@ __global__ void k_ap_sym_reduce(const float4* __restrict__ diag, const float4* _
     }
     const uint32_t i0 = item_start[b], i1 = item_start[b + 1];
     for (uint32_t i = i0; i < i1; ++i) {
+        if (i % nparts != part) continue;
         const float4 p = part_i[(size_t)i * SB + (j - b * SB)];
         x += p.x;
         y += p.y;
@@ -188,10 +197,16 @@ __global__ void k_ap_sym_reduce(const float4* __restrict__ diag, const float4* _
     }
     // pair_scale: the common mass when the pair kernel left the masses out; the within-superblock
     // term always carries its masses
-    const float4 d = diag[j];
-    x = x * (double)pair_scale + d.x;
-    y = y * (double)pair_scale + d.y;
-    z = z * (double)pair_scale + d.z;
+    // term always carries its masses; it is added by the part that owns the body
+    x *= (double)pair_scale;
+    y *= (double)pair_scale;
+    z *= (double)pair_scale;
+    if (j >= own_begin && j < own_end) {
+        const float4 d = diag[j];
+        x += d.x;
+        y += d.y;
+        z += d.z;
+    }
     acc_out[j] = make_float4(G * (float)x, G * (float)y, G * (float)z, 0.0f);
 }
 
@@ -199,6 +214,8 @@ __global__ void k_ap_sym_reduce(const float4* __restrict__ diag, const float4* _
 
 struct SymPlan {
     uint64_t n = 0;
+    uint32_t sb = 0;   // bodies per superblock
+    uint32_t seg = 0;  // source tiles per work item
     uint32_t n_items = 0;
     SymItem* items = nullptr;
     unsigned long long* rowoff = nullptr;
@@ -219,8 +236,8 @@ void nb_sym_destroy(nbody_ctx* ctx) {
 }
 
 // Bytes of scratch the symmetric path needs for n bodies (0 if it does not apply).
-uint64_t nb_sym_scratch_bytes(uint64_t n, uint32_t seg_tiles) {
-    const uint64_t nsb = (n + SB - 1) / SB, nt = (n + TILE - 1) / TILE;
+uint64_t nb_sym_scratch_bytes(uint64_t n, uint32_t seg_tiles, uint32_t SB) {
+    const uint64_t nsb = (n + SB - 1) / SB, nt = (n + TILE - 1) / TILE, TILES_PER_SB = SB / TILE;
     if (nsb < 2) return 0;
     uint64_t rows = 0, items = 0;
     for (uint64_t a = 0; a + 1 < nsb; ++a) {
@@ -231,12 +248,15 @@ uint64_t nb_sym_scratch_bytes(uint64_t n, uint32_t seg_tiles) {
     return (rows + items * SB + n) * sizeof(float4);
 }
 
-static int sym_prepare(nbody_ctx* ctx, uint32_t seg_tiles) {
-    if (ctx->sym && ctx->sym->n == ctx->n) return NBODY_OK;
+static int sym_prepare(nbody_ctx* ctx, uint32_t seg_tiles, uint32_t SB) {
+    if (ctx->sym && ctx->sym->n == ctx->n && ctx->sym->sb == SB && ctx->sym->seg == seg_tiles) return NBODY_OK;
     nb_sym_destroy(ctx);
     SymPlan* P = new SymPlan;
     ctx->sym = P;
     P->n = ctx->n;
+    P->sb = SB;
+    P->seg = seg_tiles;
+    const uint32_t TILES_PER_SB = SB / TILE;
     const uint64_t n = ctx->n;
     const uint32_t nsb = (uint32_t)((n + SB - 1) / SB), nt = (uint32_t)((n + TILE - 1) / TILE);
     std::vector<SymItem> items;
@@ -268,31 +288,37 @@ static int sym_prepare(nbody_ctx* ctx, uint32_t seg_tiles) {
     return NBODY_OK;
 }
 
-int nb_allpairs_diag(nbody_ctx* ctx, const float4* posm_in, float4* diag_out);
-
-// PLUMMER forces on all n bodies of an unsharded context.
-int nb_allpairs_forces_sym(nbody_ctx* ctx, const float4* posm_in, float4* acc_out, uint32_t seg_tiles) {
-    int r = sym_prepare(ctx, seg_tiles);
+// PLUMMER forces on all n bodies.  tpl: targets per lane (4 or 8).  part/nparts: evaluate every
+// nparts-th work item only; acc_out then holds this part's contribution to EVERY body (the
+// within-superblock term only for the context's own targets) and the parts must be summed.
+int nb_allpairs_forces_sym(nbody_ctx* ctx, const float4* posm_in, float4* acc_out, uint32_t seg_tiles, int tpl,
+                           uint32_t part, uint32_t nparts) {
+    tpl = (tpl == 8) ? 8 : 4;
+    const uint32_t SB = 256u * (uint32_t)tpl;
+    int r = sym_prepare(ctx, seg_tiles, SB);
     if (r) return r;
     SymPlan* P = ctx->sym;
     const int n = (int)ctx->n;
     nb_time_begin(ctx, 0);
     const bool uniform = ctx->uniform_mass;
     if (P->n_items) {
-        if (uniform)
-            hipLaunchKernelGGL(k_ap_sym<true>, dim3(P->n_items), dim3(256), 0, ctx->stream, posm_in, n, P->items, P->rowoff,
-                               P->part_j, P->part_i, ctx->cfg.eps2);
-        else
-            hipLaunchKernelGGL(k_ap_sym<false>, dim3(P->n_items), dim3(256), 0, ctx->stream, posm_in, n, P->items, P->rowoff,
-                               P->part_j, P->part_i, ctx->cfg.eps2);
+#define NB_SYM_LAUNCH(U, T)                                                                                          \
+    hipLaunchKernelGGL((k_ap_sym<U, T>), dim3((P->n_items + nparts - 1) / nparts), dim3(256), 0, ctx->stream, posm_in, n, \
+                       P->items, P->rowoff, P->part_j, P->part_i, ctx->cfg.eps2, part, nparts, P->n_items)
+        if (uniform && tpl == 8) NB_SYM_LAUNCH(true, 8);
+        else if (uniform) NB_SYM_LAUNCH(true, 4);
+        else if (tpl == 8) NB_SYM_LAUNCH(false, 8);
+        else NB_SYM_LAUNCH(false, 4);
+#undef NB_SYM_LAUNCH
     }
     nb_time_end(ctx, 0);
     NB_HIP(ctx, hipGetLastError());
-    r = nb_allpairs_diag(ctx, posm_in, P->diag);
+    r = nb_allpairs_diag(ctx, posm_in, P->diag, tpl);
     if (r) return r;
     hipLaunchKernelGGL(k_ap_sym_reduce, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, P->diag, P->part_j, P->part_i,
-                       P->rowoff, P->item_start, n, ctx->cfg.G, uniform ? ctx->mass0 : 1.0f, acc_out);
+                       P->rowoff, P->item_start, n, (int)SB, P->seg, ctx->cfg.G, uniform ? ctx->mass0 : 1.0f, part, nparts,
+                       (int)ctx->i_begin, (int)(ctx->i_begin + ctx->i_count), acc_out);
     NB_HIP(ctx, hipGetLastError());
-    ctx->counters.interactions_allpairs += ctx->n * ctx->n;
+    ctx->counters.interactions_allpairs += ctx->n * ctx->n / nparts;
     return NBODY_OK;
 }

@@ -247,6 +247,29 @@ int nbody_step_allpairs(nbody_ctx* ctx, int nsteps) {
     return NBODY_OK;
 }
 
+int nbody_allpairs_partial(nbody_ctx* ctx, uint32_t part, uint32_t nparts) {
+    if (!ctx) return NBODY_ERR_INVALID;
+    if (!ctx->uploaded) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_allpairs_partial: no bodies uploaded");
+    if (ctx->cfg.law != NBODY_LAW_PLUMMER || ctx->cfg.integrator != NBODY_INT_WGSL_VERLET)
+        return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_allpairs_partial: only the PLUMMER law (symmetric in the pair) with the Verlet integrator");
+    if (nparts == 0 || part >= nparts) return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_allpairs_partial: part >= nparts");
+    if (ctx->n < 4097) return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_allpairs_partial: needs at least two superblocks of bodies (N > 4096)");
+    int r = set_device(ctx);
+    if (r) return r;
+    return nb_allpairs_partial(ctx, part, nparts);
+}
+
+int nbody_integrate_partial(nbody_ctx* ctx) {
+    if (!ctx) return NBODY_ERR_INVALID;
+    if (!ctx->uploaded) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_integrate_partial: no bodies uploaded");
+    int r = set_device(ctx);
+    if (r) return r;
+    r = nb_integrate(ctx, ctx->acc_tmp);
+    if (r) return r;
+    ctx->counters.steps_allpairs += 1;
+    return NBODY_OK;
+}
+
 int nbody_step_bh(nbody_ctx* ctx, int nsteps) {
     if (!ctx) return NBODY_ERR_INVALID;
     if (!ctx->uploaded) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_step_bh: no bodies uploaded");
@@ -388,8 +411,23 @@ int nbody_device_buffer(nbody_ctx* ctx, int which, void** dev_ptr, size_t* bytes
         case NBODY_BUF_VEL: *dev_ptr = ctx->vel[ctx->cur]; if (bytes) *bytes = b16; return NBODY_OK;
         case NBODY_BUF_ACC: *dev_ptr = ctx->acc[ctx->cur]; if (bytes) *bytes = b16; return NBODY_OK;
         case NBODY_BUF_OCTREE: return nb_tree_device_nodes(ctx, dev_ptr, bytes);
+        case NBODY_BUF_ACC_PARTIAL: *dev_ptr = ctx->acc_tmp; if (bytes) *bytes = b16; return NBODY_OK;
         default: return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_device_buffer: unknown buffer");
     }
+}
+
+int nbody_read_buffer(nbody_ctx* ctx, int which, void* host_dst, size_t bytes) {
+    if (!ctx || !host_dst) return NBODY_ERR_INVALID;
+    int r = set_device(ctx);
+    if (r) return r;
+    void* dev = nullptr;
+    size_t have = 0;
+    r = nbody_device_buffer(ctx, which, &dev, &have);
+    if (r) return r;
+    if (bytes > have) return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_read_buffer: more bytes requested than the buffer holds");
+    NB_HIP(ctx, hipMemcpyAsync(host_dst, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NBODY_OK;
 }
 
 void* nbody_stream(nbody_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }

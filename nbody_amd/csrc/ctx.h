@@ -81,10 +81,12 @@ void nb_time_end(nbody_ctx* ctx, int which);
 int nb_time_collect(nbody_ctx* ctx, int which);
 
 // symmetric all-pairs (allpairs_sym.hip)
-int nb_allpairs_forces_sym(nbody_ctx* ctx, const float4* posm_in, float4* acc_out, uint32_t seg_tiles);
-uint64_t nb_sym_scratch_bytes(uint64_t n, uint32_t seg_tiles);
+int nb_allpairs_forces_sym(nbody_ctx* ctx, const float4* posm_in, float4* acc_out, uint32_t seg_tiles, int tpl,
+                           uint32_t part, uint32_t nparts);
+int nb_allpairs_partial(nbody_ctx* ctx, uint32_t part, uint32_t nparts);
+uint64_t nb_sym_scratch_bytes(uint64_t n, uint32_t seg_tiles, uint32_t sb);
 void nb_sym_destroy(nbody_ctx* ctx);
-int nb_allpairs_diag(nbody_ctx* ctx, const float4* posm_in, float4* diag_out);
+int nb_allpairs_diag(nbody_ctx* ctx, const float4* posm_in, float4* diag_out, int tpl);
 
 // octree (octree.hip)
 int nb_tree_create(nbody_ctx* ctx);

@@ -9,6 +9,12 @@ target's own velocity (src/nbody.wgsl:74-76).  For Barnes-Hut every rank rebuild
 
 The exchange is one collective per step (`all_gather_into_tensor`, RCCL over xGMI on GPUs); the
 compute backend is injected so that the exchange logic can be exercised with gloo on CPU.
+
+PLUMMER all-pairs at large N uses a second scheme, because the single-GPU kernel evaluates each
+unordered pair once and a target-sharded rank could not: the PAIR TILES of all bodies are dealt
+out over the ranks, each rank produces its contribution to every body's acceleration
+(16 bytes per body), the ranks all-reduce that buffer, integrate their own targets and
+all-gather the positions as before: two collectives per step.
 """
 import numpy as np
 import torch
@@ -33,10 +39,15 @@ class _DevicePtr:
 class HipShardBackend:
     """One rank's bodies on one MI355X through the C ABI (nbody_amd.NBodySim)."""
 
+    PAIR_SHARD_MIN_N = 65536
+
     def __init__(self, n, begin, count, device_index, **cfg):
-        from .sim import NBodySim, BUF_POSM
+        from .sim import NBodySim, BUF_POSM, BUF_ACC_PARTIAL, LAW_PLUMMER, INT_WGSL_VERLET
         torch.cuda.set_device(device_index)
         self._buf_posm = BUF_POSM
+        self._buf_partial = BUF_ACC_PARTIAL
+        self.pair_sharding = (cfg.get("law") == LAW_PLUMMER and cfg.get("integrator", INT_WGSL_VERLET) == INT_WGSL_VERLET
+                              and n >= self.PAIR_SHARD_MIN_N)
         stream = torch.cuda.current_stream().cuda_stream
         self.sim = NBodySim(n, shard_begin=begin, shard_count=count, device=device_index, stream=stream, **cfg)
         self.n = n
@@ -48,11 +59,23 @@ class HipShardBackend:
     def step(self, kind):
         (self.sim.step_bh if kind == "bh" else self.sim.step_allpairs)(1)
 
-    def posm(self):
-        ptr, _ = self.sim.device_buffer(self._buf_posm)
+    def _view(self, which):
+        ptr, _ = self.sim.device_buffer(which)
         if ptr not in self._views:
             self._views[ptr] = torch.as_tensor(_DevicePtr(ptr, self.n), device="cuda")
         return self._views[ptr]
+
+    def posm(self):
+        return self._view(self._buf_posm)
+
+    def forces_partial(self, part, nparts):
+        self.sim.allpairs_partial(part, nparts)
+
+    def acc_partial(self):
+        return self._view(self._buf_partial)
+
+    def integrate_partial(self):
+        self.sim.integrate_partial()
 
     def download(self):
         return self.sim.download()
@@ -87,8 +110,15 @@ class ShardedSim:
                                group=self.group)
 
     def step_allpairs(self, nsteps=1):
+        pair = self.world > 1 and getattr(self.backend, "pair_sharding", False)
         for _ in range(nsteps):
-            self.backend.step("allpairs")
+            if pair:
+                # every rank: its share of the pair tiles -> contributions to ALL bodies; sum them
+                self.backend.forces_partial(self.rank, self.world)
+                dist.all_reduce(self.backend.acc_partial(), op=dist.ReduceOp.SUM, group=self.group)
+                self.backend.integrate_partial()
+            else:
+                self.backend.step("allpairs")
             self.exchange()
 
     def step_bh(self, nsteps=1):

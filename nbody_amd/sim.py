@@ -15,7 +15,7 @@ from ._lib import NBodyConfig, NBodyCounters
 
 LAW_CPU_R6, LAW_WGSL_BIAS, LAW_PLUMMER = 0, 1, 2
 INT_CPU_EULER_XBUF, INT_WGSL_VERLET = 0, 1
-BUF_POSM, BUF_VEL, BUF_ACC, BUF_OCTREE = 0, 1, 2, 3
+BUF_POSM, BUF_VEL, BUF_ACC, BUF_OCTREE, BUF_ACC_PARTIAL = 0, 1, 2, 3, 4
 NODE_DUMMY, NODE_LEAFBODY, NODE_LEAFLIST, NODE_INTERIOR = 0, 1, 2, 3
 
 # the 96-byte node of src/nbodybh.wgsl:1-9 as a numpy record
@@ -137,6 +137,12 @@ class NBodySim:
     def step_bh(self, nsteps=1):
         self._ck(self.lib.nbody_step_bh(self.h, nsteps))
 
+    def allpairs_partial(self, part, nparts):
+        self._ck(self.lib.nbody_allpairs_partial(self.h, part, nparts))
+
+    def integrate_partial(self):
+        self._ck(self.lib.nbody_integrate_partial(self.h))
+
     def accel_allpairs(self):
         a = np.zeros((self.n, 4), np.float32)
         self._ck(self.lib.nbody_accel_allpairs(self.h, _ptr(a)))
@@ -203,6 +209,12 @@ class NBodySim:
         p, b = C.c_void_p(), C.c_size_t()
         self._ck(self.lib.nbody_device_buffer(self.h, which, C.byref(p), C.byref(b)))
         return p.value, b.value
+
+    def read_buffer(self, which):
+        """Host copy of one of the f32[N][4] device buffers (BUF_POSM/VEL/ACC/ACC_PARTIAL)."""
+        out = np.empty((self.n, 4), np.float32)
+        self._ck(self.lib.nbody_read_buffer(self.h, which, _ptr(out), out.nbytes))
+        return out
 
     def stream(self):
         return self.lib.nbody_stream(self.h)

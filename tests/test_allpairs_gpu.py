@@ -223,3 +223,49 @@ def test_symmetric_pair_path_matches_plain_path(orc, monkeypatch, n):
             assert np.array_equal(outs[sym], a2)     # reproducible bit for bit
     check_acc(orc, 2, m, pos, vel, outs["1"])
     assert body_rel_err(outs["1"], outs["0"]).max() < TOL
+
+
+def test_default_path_at_config2_size(orc):
+    """All-pairs N = 65,536 on one GPU (the reference's GPU semantics, PLUMMER law): whatever path
+    the library picks by default, against the float64 oracle on a sample of targets."""
+    import nbody_amd as nb
+    n = 65536
+    m, pos = orc.gen_plummer(n, seed=42)
+    vel = np.zeros((n, 4), np.float32)
+    with nb.NBodySim(n, law=2) as sim:
+        sim.upload(m, pos, vel)
+        acc = sim.accel_allpairs()
+    sample = np.arange(0, n, 64)
+    worst = 0.0
+    for i0 in (0, 30000, 65000):
+        cnt = 512
+        ref64 = orc.accel_allpairs_f64(2, pos, vel, m, i_begin=i0, i_count=cnt)
+        e = np.linalg.norm(acc[i0:i0 + cnt, :3] - ref64, axis=1) / np.linalg.norm(ref64, axis=1)
+        worst = max(worst, e.max())
+    assert worst < TOL, worst
+
+
+def test_pair_parts_sum_to_the_whole(orc):
+    """nbody_allpairs_partial: the parts (one per GPU in production; here run one after another
+    on one GPU) sum to the unsharded accelerations, and the within-superblock term appears only
+    in the part that owns the body."""
+    import nbody_amd as nb
+    n = 20000
+    m, pos = orc.gen_plummer(n, seed=4)
+    m = (m * (1.0 + 0.3 * np.cos(np.arange(n)))).astype(np.float32)
+    with nb.NBodySim(n, law=2) as sim:
+        sim.upload(m, pos)
+        whole = sim.accel_allpairs()
+    total = np.zeros((n, 4), np.float64)
+    nparts = 3
+    for part in range(nparts):
+        b, c = [(0, 7000), (7000, 7000), (14000, 6000)][part]
+        with nb.NBodySim(n, law=2, shard_begin=b, shard_count=c) as sim:
+            sim.upload(m, pos)
+            sim.allpairs_partial(part, nparts)
+            total += sim.read_buffer(nb.BUF_ACC_PARTIAL)
+            if part == 0:   # integrate with the un-summed buffer: only checks the call sequence
+                sim.integrate_partial()
+                p1, v1, a1 = sim.download()
+                assert np.array_equal(p1[b:b + c, :3], pos[b:b + c, :3]) and np.all(v1[b + c:] == 0)
+    assert body_rel_err(total, whole).max() < 2e-6

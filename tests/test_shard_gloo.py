@@ -20,9 +20,11 @@ if ROOT not in sys.path:
 class OracleShardBackend:
     """Test stand-in for HipShardBackend: same interface, oracle arithmetic on host tensors."""
 
-    def __init__(self, n, begin, count, law):
+    def __init__(self, n, begin, count, law, pair_sharding=False):
         from oracle import oracle as orc
         self.orc, self.n, self.b, self.c, self.law = orc, n, begin, count, law
+        self.pair_sharding = pair_sharding
+        self.partial = torch.zeros(n, 4)
         self.full = torch.zeros(n, 4)          # packed {x,y,z,m}: the buffer the ranks all-gather
         self.vel = np.zeros((n, 4), np.float32)
         self.acc = np.zeros((n, 4), np.float32)
@@ -37,6 +39,32 @@ class OracleShardBackend:
 
     def posm(self):
         return self.full
+
+    # pair-sharded scheme: this part's contribution to every body's acceleration.  Any partition
+    # of the pair set whose parts sum to the whole exercises the exchange; here part p takes the
+    # sources j with j % nparts == p.
+    def forces_partial(self, part, nparts):
+        f = self.full.numpy()
+        pos = np.zeros((self.n, 4), np.float32)
+        pos[:, :3] = f[:, :3]
+        sel = np.arange(part, self.n, nparts)
+        m = np.zeros_like(self.m)
+        m[sel] = self.m[sel]                 # the other sources weigh nothing in this part
+        a = self.orc.accel_allpairs(self.law, pos, self.vel, m)
+        self.partial.numpy()[:] = a
+
+    def acc_partial(self):
+        return self.partial
+
+    def integrate_partial(self):
+        orc, s = self.orc, slice(self.b, self.b + self.c)
+        f = self.full.numpy()
+        pos = np.zeros((self.n, 4), np.float32)
+        pos[:, :3] = f[:, :3]
+        a = self.partial.numpy()
+        po, vo, ao = orc.integrate_wgsl(pos[s], self.vel[s], self.acc[s], a[s])
+        f[s, :3] = po[:, :3]
+        self.vel[s], self.acc[s] = vo, ao
 
     def step(self, kind):
         orc, b, c = self.orc, self.b, self.c
@@ -62,7 +90,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, law, kind, steps, out_dir):
+def _worker(rank, world, port, n, law, kind, steps, out_dir, pair=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, ROOT)
@@ -76,7 +104,7 @@ def _worker(rank, world, port, n, law, kind, steps, out_dir):
         vel = np.zeros((n, 4), np.float32)
         vel[:, :3] = 0.2 * (orc.gen_refcube(n, seed=9)[1][:, :3] / 125.0 - 1.0)
         b, c = shard_range(n, rank, world)
-        be = OracleShardBackend(n, b, c, law)
+        be = OracleShardBackend(n, b, c, law, pair_sharding=pair)
         be.upload(m, pos, vel)
         sim = ShardedSim(be, n)
         assert (sim.begin, sim.count) == (b, c)
@@ -87,9 +115,9 @@ def _worker(rank, world, port, n, law, kind, steps, out_dir):
         dist.destroy_process_group()
 
 
-def _run(world, n, law, kind, steps, tmp_path):
+def _run(world, n, law, kind, steps, tmp_path, pair=False):
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, n, law, kind, steps, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, n, law, kind, steps, str(tmp_path), pair), nprocs=world, join=True)
     from nbody_amd.shard import shard_range
     full = [np.load(tmp_path / f"posm_{r}.npy") for r in range(world)]
     vel = np.zeros((n, 4), np.float32)
@@ -132,3 +160,17 @@ def test_sharded_bh_equals_unsharded(orc, tmp_path):
     for f in full:
         assert np.array_equal(f[:, :3], rp[:, :3])
     assert np.array_equal(vel, rv)
+
+
+def test_pair_sharded_allpairs_matches_unsharded(orc, tmp_path):
+    """The two-collective scheme (all-reduce of partial accelerations, then all-gather of
+    positions): the parts' sums differ from the unsharded sum only by f32 summation order."""
+    world, n, steps, law = 2, 384, 3, orc.LAW_PLUMMER
+    full, vel = _run(world, n, law, "allpairs", steps, tmp_path, pair=True)
+    m, pos = orc.gen_refcube(n, seed=8)
+    v0 = np.zeros((n, 4), np.float32)
+    v0[:, :3] = 0.2 * (orc.gen_refcube(n, seed=9)[1][:, :3] / 125.0 - 1.0)
+    rp, rv, ra = orc.step_wgsl_allpairs(law, m, pos, v0, np.zeros_like(pos), steps)
+    assert np.array_equal(full[0], full[1])           # both ranks hold the same gathered state
+    assert np.abs(full[0][:, :3] - rp[:, :3]).max() < 1e-5
+    assert np.abs(vel - rv).max() < 1e-7

@@ -144,6 +144,34 @@ def main():
         out["wgsl_bias_law"] = {"value": float(n) * n * wsteps / wdt, "unit": "interactions/s",
                                 "ms_per_step": wdt / wsteps * 1e3, "achieved_tflops": wach,
                                 "frac": wach / PEAK_FP32_TFLOPS, "steps": wsteps}
+    if not args.no_extras and world == 1:
+        # Barnes-Hut step (octree build + traversal + integrate/clamp), N = 1M, theta = 0.5, one GPU
+        with nb.NBodySim(n, law=nb.LAW_PLUMMER) as sim:
+            sim.upload(masses, pos, vel)
+            sim.step_bh(2)
+            sim.set_counting(True)
+            sim.accel_bh()
+            c = sim.counters()
+            sim.set_counting(False)
+            sim.set_kernel_timing(True)
+            sim.kernel_time(bh=True)
+            sim.sync()
+            t0 = time.perf_counter()
+            bsteps = 20
+            sim.step_bh(bsteps)
+            sim.sync()
+            bdt = time.perf_counter() - t0
+            wms, _ = sim.kernel_time(bh=True)
+        inter = c["bh_leaf_interactions"] + c["bh_aggregate_interactions"]
+        # bytes the traversal asks for: 32 B per wavefront node visit + per-body reads/writes
+        walk_bytes = 32.0 * c["bh_wave_node_visits"] + n * (16 + 16 + 16)
+        out["barnes_hut"] = {"n_bodies": n, "theta": 0.5, "max_depth": 16, "steps_per_s": bsteps / bdt,
+                             "ms_per_step": bdt / bsteps * 1e3, "walk_kernel_ms": wms, "octree_nodes": c["octree_nodes"],
+                             "interactions_per_step": inter, "interactions_per_s": inter * bsteps / bdt,
+                             "node_visits_per_body": c["bh_node_visits"] / n,
+                             "wave_node_visits": c["bh_wave_node_visits"],
+                             "walk_requested_GBps": walk_bytes / (wms * 1e-3) / 1e9 if wms > 0 else None,
+                             "equivalent_allpairs_interactions_per_s": float(n) * n * bsteps / bdt}
     if rank == 0 and args.gpus == 1 and not args.no_extras:
         try:
             out["cpu_baseline"] = cpu_baseline()

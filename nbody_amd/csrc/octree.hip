@@ -70,6 +70,7 @@ struct Octree {
     uint32_t h_lvl_start[NCNT + 1] = {0};
     // nodes
     WNode* nodes = nullptr;
+    struct QNodeOpaque* walk = nullptr;  // QNode[cap_nodes]
     float4* bmin = nullptr;
     float4* bmax = nullptr;
     uint64_t cap_nodes = 0;
@@ -528,16 +529,55 @@ __global__ __launch_bounds__(1024) void k_compact_order(const uint32_t* __restri
 }
 
 // ---- traversal ----------------------------------------------------------------------------
-constexpr int WALK_STACK = 160;  // >= 8 children x 17 levels + root
+// Walk record (32 B, one s_load_dwordx8): the children of a node are CONTIGUOUS (breadth-first
+// numbering; uploaded trees are renumbered on the host), so a node that must be opened is pushed
+// as (first child, count, lane mask) and its children are fetched together when it is popped.
+struct QNode {
+    float cx, cy, cz, mass;
+    float range;
+    uint32_t type;
+    uint32_t first;  // first child (INTERIOR) or first list member (LEAFLIST)
+    uint32_t count;  // children / list members
+};
+static_assert(sizeof(QNode) == 32, "walk record layout");
+
+__global__ void k_make_walk(const WNode* __restrict__ nodes, uint32_t count, QNode* __restrict__ q,
+                            uint32_t* __restrict__ err_flag) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= count) return;
+    const WNode nd = nodes[id];
+    QNode o;
+    o.cx = nd.cx; o.cy = nd.cy; o.cz = nd.cz; o.mass = nd.mass;
+    o.range = nd.range;
+    o.type = nd.type;
+    o.first = 0;
+    o.count = 0;
+    if (nd.type == NBODY_NODE_INTERIOR) {
+        uint32_t last = 0;
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t c = nd.child[k];
+            if (c == 0) continue;
+            if (o.count == 0) o.first = c;
+            else if (c != last + 1) *err_flag = 3;  // children must be consecutive in octant order
+            last = c;
+            ++o.count;
+        }
+    } else if (nd.type == NBODY_NODE_LEAFLIST) {
+        o.first = nd.child[0];
+        o.count = max(nd.child[1], 1u);  // src/nbodybh.wgsl:139-146 is a do-while: at least one member
+    }
+    q[id] = o;
+}
+
+constexpr int WALK_STACK = 160;  // >= 8 pushes per level x 17 levels + root
 
 template <int LAW, bool COUNT>
-__global__ __launch_bounds__(256) void k_walk(const WNode* __restrict__ nodes, const uint32_t* __restrict__ order,
-                                              uint32_t m, uint32_t i_begin, const float4* __restrict__ posm,
+__global__ __launch_bounds__(256) void k_walk(const QNode* __restrict__ q, const uint32_t* __restrict__ order, uint32_t m,
+                                              uint32_t i_begin, const float4* __restrict__ posm,
                                               const float4* __restrict__ vel, float4* __restrict__ acc_out, float G,
                                               float eps2, float theta, unsigned long long* __restrict__ counters,
                                               uint32_t* __restrict__ err_flag) {
-    __shared__ uint32_t st_id[4][WALK_STACK];
-    __shared__ unsigned long long st_mask[4][WALK_STACK];
+    __shared__ uint4 st[4][WALK_STACK];  // {first, count, mask.lo, mask.hi}
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t r = blockIdx.x * 256 + tid;
     const bool valid = r < m;
@@ -556,77 +596,72 @@ __global__ __launch_bounds__(256) void k_walk(const WNode* __restrict__ nodes, c
     }
     float ax = 0.0f, ay = 0.0f, az = 0.0f;
     uint32_t n_visit = 0, n_leaf = 0, n_agg = 0, n_wave = 0, max_top = 0;
+    // The acceptance test is src/nbodybh.wgsl:104-106, range / distance < theta, with IEEE
+    // division and square root.  A cheap estimate (range * rsq(r^2), relative error < 1e-6)
+    // settles every case outside a 2e-6 band around theta; inside it the exact expression decides.
+    const float th_lo = theta * (1.0f - 2e-6f), th_hi = theta * (1.0f + 2e-6f);
 
-    uint32_t* sid = st_id[wave];
-    unsigned long long* smask = st_mask[wave];
+    uint4* stack = st[wave];
     int top = 0;
     const unsigned long long all = __ballot(valid);
     if (all) {
-        sid[0] = 0;
-        smask[0] = all;
+        stack[0] = make_uint4(0u, 1u, (uint32_t)all, (uint32_t)(all >> 32));  // the root as a one-node group
         top = 1;
     }
     while (top > 0) {
         --top;
-        const uint32_t id = __builtin_amdgcn_readfirstlane(sid[top]);
-        const unsigned long long mk = smask[top];
-        const uint32_t mlo = __builtin_amdgcn_readfirstlane((uint32_t)mk);
-        const uint32_t mhi = __builtin_amdgcn_readfirstlane((uint32_t)(mk >> 32));
-        const unsigned long long mask = ((unsigned long long)mhi << 32) | mlo;
+        const uint4 e = stack[top];
+        const uint32_t first = __builtin_amdgcn_readfirstlane(e.x);
+        const uint32_t cnt = __builtin_amdgcn_readfirstlane(e.y);
+        // (readfirstlane returns int: go through uint32_t, or the low half sign-extends over the high)
+        const uint32_t mlo = (uint32_t)__builtin_amdgcn_readfirstlane(e.z);
+        const uint32_t mhi = (uint32_t)__builtin_amdgcn_readfirstlane(e.w);
+        const unsigned long long mask = ((unsigned long long)mhi << 32) | (unsigned long long)mlo;
         const bool active = (mask >> lane) & 1ull;
-        const WNode nd = nodes[id];
-        if (COUNT) {
-            n_wave += (lane == 0);
-            n_visit += active;
-        }
-        const float4 src = make_float4(nd.cx, nd.cy, nd.cz, nd.mass);
-        if (nd.type == NBODY_NODE_LEAFBODY) {  // src/nbodybh.wgsl:76-102
-            if (active) {
-                interact<LAW, false, true>(t, src, 0, eps2, ax, ay, az);
-                if (COUNT) ++n_leaf;
-            }
-        } else {
-            // src/nbodybh.wgsl:104-106: d / r < theta with r = distance(pos, com)
-            const float dx = t.x - nd.cx, dy = t.y - nd.cy, dz = t.z - nd.cz;
-            const float rr = sqrtf(((dx * dx) + (dy * dy)) + (dz * dz));
-            const bool accept = (nd.range / rr) < theta;
-            if (active && accept) {
-                interact<LAW, false, true>(t, src, 0, eps2, ax, ay, az);
-                if (COUNT) ++n_agg;
-            }
-            const unsigned long long open = __ballot(active && !accept);
-            if (open) {
-                if (nd.type == NBODY_NODE_LEAFLIST) {
-                    // src/nbodybh.wgsl:137-146: members pushed ascending (at least one), so they are
-                    // popped next, highest first; they are LEAFBODY nodes and push nothing themselves
-                    const uint32_t first = nd.child[0];
-                    const uint32_t cnt = max(nd.child[1], 1u);
-                    const bool mine = (open >> lane) & 1ull;
-                    for (uint32_t k = cnt; k-- > 0;) {
-                        const WNode c = nodes[first + k];
-                        if (COUNT) {
-                            n_wave += (lane == 0);
-                            n_visit += mine;
-                        }
-                        if (mine) {
-                            interact<LAW, false, true>(t, make_float4(c.cx, c.cy, c.cz, c.mass), 0, eps2, ax, ay, az);
-                            if (COUNT) ++n_leaf;
-                        }
-                    }
-                } else {  // src/nbodybh.wgsl:148-157
-                    if (top + 8 > WALK_STACK) {
-                        if (lane == 0) *err_flag = 2;
-                        break;
-                    }
+        for (uint32_t b0 = 0; b0 < cnt; b0 += 8) {
+            const uint32_t nb = min(8u, cnt - b0);
+            QNode c[8];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const uint32_t c = nd.child[k];
-                        if (c != 0u) {
-                            sid[top] = c;
-                            smask[top] = open;
-                            ++top;
-                        }
+            for (int k = 0; k < 8; ++k) c[k] = q[first + b0 + min((uint32_t)k, nb - 1)];  // all fetched before the first use
+            if (top + 8 > WALK_STACK) {
+                if (lane == 0) *err_flag = 2;
+                top = 0;
+                break;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if ((uint32_t)k >= nb) break;
+                const QNode nd = c[k];
+                if (COUNT) {
+                    n_wave += (lane == 0);
+                    n_visit += active;
+                }
+                const float4 src = make_float4(nd.cx, nd.cy, nd.cz, nd.mass);
+                if (nd.type == NBODY_NODE_LEAFBODY) {  // src/nbodybh.wgsl:76-102
+                    if (active) {
+                        interact<LAW, false, true>(t, src, 0, eps2, ax, ay, az);
+                        if (COUNT) ++n_leaf;
                     }
+                    continue;
+                }
+                const float dx = t.x - nd.cx, dy = t.y - nd.cy, dz = t.z - nd.cz;
+                const float est = nd.range * __builtin_amdgcn_rsqf(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
+                bool accept = est < th_lo;
+                const bool unsure = !accept && !(est > th_hi);
+                if (__any(active && unsure)) {
+                    const float rr = sqrtf(((dx * dx) + (dy * dy)) + (dz * dz));  // distance(pos, com)
+                    const bool exact = (nd.range / rr) < theta;
+                    accept = unsure ? exact : accept;
+                }
+                if (active && accept) {
+                    interact<LAW, false, true>(t, src, 0, eps2, ax, ay, az);
+                    if (COUNT) ++n_agg;
+                }
+                const unsigned long long open = __ballot(active && !accept);
+                if (open) {
+                    // INTERIOR: its children; LEAFLIST: its members (LEAFBODY records, src/nbodybh.wgsl:137-146)
+                    stack[top] = make_uint4(nd.first, nd.count, (uint32_t)open, (uint32_t)(open >> 32));
+                    ++top;
                     if (COUNT) max_top = max(max_top, (uint32_t)top);
                 }
             }
@@ -647,12 +682,15 @@ int ensure_nodes(nbody_ctx* ctx, Octree* T, uint64_t need) {
     uint64_t cap = std::max<uint64_t>(need + need / 4 + 1024, 2 * T->n + 1024);
     if (cap > 0xfffffff0ull) return nb_fail(ctx, NBODY_ERR_CAPACITY, "octree needs more than 2^32 nodes");
     if (T->nodes) NB_HIP(ctx, hipFree(T->nodes));
+    if (T->walk) NB_HIP(ctx, hipFree(T->walk));
+    T->walk = nullptr;
     if (T->bmin) NB_HIP(ctx, hipFree(T->bmin));
     if (T->bmax) NB_HIP(ctx, hipFree(T->bmax));
     T->nodes = nullptr;
     T->bmin = T->bmax = nullptr;
     T->cap_nodes = 0;
     NB_HIP(ctx, hipMalloc(&T->nodes, cap * sizeof(WNode)));
+    NB_HIP(ctx, hipMalloc(&T->walk, cap * sizeof(QNode)));
     NB_HIP(ctx, hipMalloc(&T->bmin, cap * sizeof(float4)));
     NB_HIP(ctx, hipMalloc(&T->bmax, cap * sizeof(float4)));
     T->cap_nodes = cap;
@@ -666,7 +704,9 @@ int check_err_flag(nbody_ctx* ctx, Octree* T, const char* what) {
     if (h) {
         NB_HIP(ctx, hipMemsetAsync(T->err_flag, 0, sizeof(uint32_t), ctx->stream));
         return nb_fail(ctx, NBODY_ERR_CAPACITY,
-                       std::string(what) + (h == 2 ? ": traversal stack overflow" : ": node capacity exceeded"));
+                       std::string(what) + (h == 2 ? ": traversal stack overflow"
+                                            : h == 3 ? ": children of a node are not consecutive"
+                                                     : ": node capacity exceeded"));
     }
     return NBODY_OK;
 }
@@ -676,11 +716,11 @@ void launch_walk(nbody_ctx* ctx, Octree* T, const uint32_t* order, uint32_t m, c
                  float4* acc_out) {
     dim3 grid((m + 255) / 256);
     if (ctx->counting)
-        hipLaunchKernelGGL((k_walk<LAW, true>), grid, dim3(256), 0, ctx->stream, T->nodes, order, m, (uint32_t)ctx->i_begin,
+        hipLaunchKernelGGL((k_walk<LAW, true>), grid, dim3(256), 0, ctx->stream, (const QNode*)T->walk, order, m, (uint32_t)ctx->i_begin,
                            posm, vel, acc_out, ctx->cfg.G, ctx->cfg.eps2, ctx->cfg.theta,
                            (unsigned long long*)T->walk_counters, T->err_flag);
     else
-        hipLaunchKernelGGL((k_walk<LAW, false>), grid, dim3(256), 0, ctx->stream, T->nodes, order, m, (uint32_t)ctx->i_begin,
+        hipLaunchKernelGGL((k_walk<LAW, false>), grid, dim3(256), 0, ctx->stream, (const QNode*)T->walk, order, m, (uint32_t)ctx->i_begin,
                            posm, vel, acc_out, ctx->cfg.G, ctx->cfg.eps2, ctx->cfg.theta,
                            (unsigned long long*)T->walk_counters, T->err_flag);
 }
@@ -724,7 +764,7 @@ void nb_tree_destroy(nbody_ctx* ctx) {
         if (T->idx[s]) hipFree(T->idx[s]);
     }
     void* ptrs[] = {T->lo, T->top, T->flags, T->body_node, T->rs_counts, T->row_total, T->row_base, T->blk,
-                    T->lvl_total, T->lvl_start, T->nodes, T->bmin, T->bmax, T->export_buf, T->shard_order,
+                    T->lvl_total, T->lvl_start, T->nodes, T->walk, T->bmin, T->bmax, T->export_buf, T->shard_order,
                     T->walk_counters, T->err_flag};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -779,6 +819,8 @@ int nb_tree_build(nbody_ctx* ctx, const float4* posm_in) {
         if (!count) continue;
         hipLaunchKernelGGL(k_aggregate, dim3((count + 255) / 256), dim3(256), 0, st, T->nodes, T->bmin, T->bmax, first, count);
     }
+    hipLaunchKernelGGL(k_make_walk, dim3(((uint32_t)total + 255) / 256), dim3(256), 0, st, T->nodes, (uint32_t)total,
+                       (QNode*)T->walk, T->err_flag);
     NB_HIP(ctx, hipGetLastError());
     T->have_tree = true;
     T->built = true;
@@ -857,37 +899,70 @@ int nb_tree_device_nodes(nbody_ctx* ctx, void** ptr, size_t* bytes) {
 
 int nb_tree_upload(nbody_ctx* ctx, const nbody_octree_node* host_nodes, uint64_t n_nodes) {
     Octree* T = ctx->tree;
-    int r = ensure_nodes(ctx, T, n_nodes);
-    if (r) return r;
-    // validate child indices on the host: the traversal trusts them
-    for (uint64_t i = 0; i < n_nodes; ++i) {
-        const nbody_octree_node& nd = host_nodes[i];
+    // The traversal wants the children of a node (and the members of a leaf list) consecutive.
+    // Renumber breadth-first on the host, validating the indices on the way: the reference's
+    // allocation order (src/octree_maxdepth.rs:188-194) does not have that property.
+    std::vector<uint32_t> new_id(n_nodes, NO_NODE);
+    std::vector<uint32_t> bfs;  // bfs[new] = old
+    bfs.reserve(n_nodes);
+    new_id[0] = 0;
+    bfs.push_back(0);
+    for (size_t head = 0; head < bfs.size(); ++head) {
+        const nbody_octree_node& nd = host_nodes[bfs[head]];
         if (nd.node_type > NBODY_NODE_INTERIOR) return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_upload_octree: bad node_type");
-        if (nd.node_type == NBODY_NODE_LEAFLIST) {
-            if ((uint64_t)nd.child_indices[0] + std::max<uint32_t>(nd.child_indices[1], 1u) > n_nodes)
-                return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_upload_octree: leaf list outside the node array");
-        } else if (nd.node_type == NBODY_NODE_INTERIOR) {
-            for (int k = 0; k < 8; ++k)
-                if (nd.child_indices[k] >= n_nodes) return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_upload_octree: child index outside the node array");
+        if (nd.node_type == NBODY_NODE_INTERIOR) {
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t c = nd.child_indices[k];
+                if (c == 0) continue;
+                if (c >= n_nodes) return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_upload_octree: child index outside the node array");
+                if (new_id[c] != NO_NODE) return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_upload_octree: a node has two parents");
+                new_id[c] = (uint32_t)bfs.size();
+                bfs.push_back(c);
+            }
+        } else if (nd.node_type == NBODY_NODE_LEAFLIST) {
+            const uint64_t first = nd.child_indices[0], cnt = std::max<uint32_t>(nd.child_indices[1], 1u);
+            if (first + cnt > n_nodes) return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_upload_octree: leaf list outside the node array");
+            for (uint64_t c = first; c < first + cnt; ++c) {
+                if (c == 0 || new_id[c] != NO_NODE) return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_upload_octree: a node has two parents");
+                if (host_nodes[c].node_type != NBODY_NODE_LEAFBODY)
+                    return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_upload_octree: leaf-list members must be LEAFBODY nodes");
+                new_id[c] = (uint32_t)bfs.size();
+                bfs.push_back((uint32_t)c);
+            }
         }
     }
-    if (T->export_cap < n_nodes) {
+    const uint64_t kept = bfs.size();
+    std::vector<nbody_octree_node> renum(kept);
+    for (uint64_t i = 0; i < kept; ++i) {
+        nbody_octree_node nd = host_nodes[bfs[i]];
+        if (nd.node_type == NBODY_NODE_INTERIOR) {
+            for (int k = 0; k < 8; ++k)
+                if (nd.child_indices[k]) nd.child_indices[k] = new_id[nd.child_indices[k]];
+        } else if (nd.node_type == NBODY_NODE_LEAFLIST) {
+            nd.child_indices[0] = new_id[nd.child_indices[0]];
+        }
+        renum[i] = nd;
+    }
+    int r = ensure_nodes(ctx, T, kept);
+    if (r) return r;
+    if (T->export_cap < kept) {
         if (T->export_buf) NB_HIP(ctx, hipFree(T->export_buf));
         T->export_buf = nullptr;
         T->export_cap = 0;
         NB_HIP(ctx, hipMalloc(&T->export_buf, T->cap_nodes * sizeof(nbody_octree_node)));
         T->export_cap = T->cap_nodes;
     }
-    NB_HIP(ctx, hipMemcpyAsync(T->export_buf, host_nodes, n_nodes * sizeof(nbody_octree_node), hipMemcpyHostToDevice, ctx->stream));
-    const uint32_t cnt = (uint32_t)n_nodes;
+    NB_HIP(ctx, hipMemcpyAsync(T->export_buf, renum.data(), kept * sizeof(nbody_octree_node), hipMemcpyHostToDevice, ctx->stream));
+    const uint32_t cnt = (uint32_t)kept;
     hipLaunchKernelGGL(k_import, dim3((cnt + 255) / 256), dim3(256), 0, ctx->stream, T->export_buf, cnt, T->nodes, T->bmin, T->bmax);
+    hipLaunchKernelGGL(k_make_walk, dim3((cnt + 255) / 256), dim3(256), 0, ctx->stream, T->nodes, cnt, (QNode*)T->walk, T->err_flag);
     NB_HIP(ctx, hipGetLastError());
     NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    T->n_nodes = n_nodes;
+    T->n_nodes = kept;
     T->have_tree = true;
     T->built = false;  // no sorted order for this tree: targets are walked in index order
-    ctx->counters.octree_nodes = n_nodes;
-    return NBODY_OK;
+    ctx->counters.octree_nodes = kept;
+    return check_err_flag(ctx, T, "nbody_upload_octree");
 }
 
 int nb_tree_keys(nbody_ctx* ctx, uint64_t* keys, uint8_t* depth, uint32_t* order) {

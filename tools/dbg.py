@@ -1,12 +1,11 @@
 import sys; sys.path.insert(0,'/root/repo')
 import numpy as np, nbody_amd as nb
-g=np.load('/root/repo/tests/golden/refcube_n4096_s1.npz')
-m,pos,vel=g['masses'],g['pos'],g['vel']; n=len(m)
-for name,law in (("cpu_r6",0),("wgsl_bias",1),("plummer",2)):
-    with nb.NBodySim(n, law=law) as sim:
-        sim.upload(m,pos,vel); acc=sim.accel_allpairs()
-    ref64=g[f"acc64_{name}"]; e=np.linalg.norm(acc[:,:3]-ref64,axis=1); e_ref=np.linalg.norm(g[f"acc_{name}"][:,:3]-ref64,axis=1)
-    s=np.linalg.norm(ref64,axis=1)
-    bad=e>1e-5*s+e_ref
-    print(name, bad.sum(), (e/s).max(), (e_ref/s).max(), np.median(e/s), np.median(e_ref/s))
-    i=np.argmax(e/s - e_ref/s); print(i, e[i]/s[i], e_ref[i]/s[i], acc[i], ref64[i], g[f"acc_{name}"][i])
+from oracle import oracle as orc
+for n in (2,3,5,9,20,64,65,200,1000):
+    m,pos=orc.gen_refcube(n,seed=3)
+    vel=np.zeros((n,4),np.float32)
+    nodes,_,_,_=orc.build_octree(pos,m)
+    ref,cnt=orc.bh_accel(2,pos,vel,nodes)
+    with nb.NBodySim(n, law=2) as sim:
+        sim.upload(m,pos,vel); sim.build_octree(); sim.set_counting(True); acc=sim.accel_bh(); c=sim.counters()
+    print(n, len(nodes), (c["bh_node_visits"],c["bh_leaf_interactions"],c["bh_aggregate_interactions"]), (cnt["visits"],cnt["leaf"],cnt["aggregate"]), np.abs(acc-ref).max())

@@ -136,6 +136,16 @@ def main():
                              "evaluates each unordered pair once (Newton's third law), so it executes about half of "
                              "those flops; the plain kernel (one evaluation per ordered pair) reaches 0.57 of peak"},
     }
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process;
+    # the value measured with rocprofv3 (separate FETCH_SIZE / WRITE_SIZE passes over this same
+    # command) is kept under profiles/ and quoted when it is for this workload.
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_allpairs.json")))
+        if (pmc["n_bodies"], pmc["n_gpus"], pmc["law"]) == (n, args.gpus, args.law) and out["roofline"]["kernel"] in pmc["kernels"]:
+            out["roofline"]["traffic"] = pmc["kernels"][out["roofline"]["kernel"]]["hbm_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = "profiles/r01_pmc_allpairs.json (rocprofv3 --pmc, offline)"
+    except (OSError, KeyError, ValueError):
+        pass
     if not args.no_extras and args.law == "plummer":
         # the reference's shader law (src/nbody.wgsl:54-81) on the same bodies, fewer steps
         wsteps = max(1, min(2, args.steps))

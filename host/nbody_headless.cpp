@@ -50,7 +50,7 @@ int main(int argc, char** argv) {
         if (rc) return die(ctx, "step", rc);
         if (report > 0 && f % report == 0) {
             if ((rc = nbody_download(ctx, pos.data(), nullptr, nullptr))) return die(ctx, "nbody_download", rc);
-            std::printf("frame %d: body0 = (%.5f, %.5f, %.5f)\n", f, pos[0], pos[1], pos[2]);
+            std::printf("frame %d: body0 = (%.9g, %.9g, %.9g)\n", f, pos[0], pos[1], pos[2]);
         }
     }
     nbody_sync(ctx);

@@ -39,6 +39,59 @@ __device__ __forceinline__ void interact_plummer_pk(const f2 px, const f2 py, co
     az = __builtin_elementwise_fma(sc, dz, az);
 }
 
+// WGSL_BIAS for two targets per packed register pair: src/nbody.wgsl:56-81 with every lane-op
+// that has a packed form packed; the six transcendentals per target stay scalar.
+__device__ __forceinline__ void interact_bias_pk(const f2 px, const f2 py, const f2 pz, const f2 vx, const f2 vy,
+                                                 const f2 vz, const f2 vn, const float4 s, float eps2, f2& ax, f2& ay,
+                                                 f2& az) {
+    const f2 dx = s.x - px, dy = s.y - py, dz = s.z - pz;
+    const f2 r2u = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, dz * dz));
+    const f2 r2s = r2u + eps2;
+    f2 dist, rinv;
+    dist.x = __builtin_amdgcn_sqrtf(r2u.x);
+    dist.y = __builtin_amdgcn_sqrtf(r2u.y);
+    rinv.x = __builtin_amdgcn_rsqf(r2s.x);
+    rinv.y = __builtin_amdgcn_rsqf(r2s.y);
+    f2 sc = (s.w * rinv) * (rinv * rinv);
+    const f2 vd = __builtin_elementwise_fma(vx, dx, __builtin_elementwise_fma(vy, dy, vz * dz));
+    const f2 den = __builtin_elementwise_fma(dist, vn, (f2)1.0f);
+    f2 rden;
+    rden.x = __builtin_amdgcn_rcpf(den.x);
+    rden.y = __builtin_amdgcn_rcpf(den.y);
+    const f2 q = vd * rden;
+    // acos(q) = sqrt(1-|q|) * P7(|q|), reflected for q < 0 (see fast_acos)
+    f2 a;
+    a.x = fminf(fabsf(q.x), 1.0f);
+    a.y = fminf(fabsf(q.y), 1.0f);
+    f2 p = (f2)-0.0012624911f;
+    p = __builtin_elementwise_fma(p, a, (f2)0.0066700901f);
+    p = __builtin_elementwise_fma(p, a, (f2)-0.0170881256f);
+    p = __builtin_elementwise_fma(p, a, (f2)0.0308918810f);
+    p = __builtin_elementwise_fma(p, a, (f2)-0.0501743046f);
+    p = __builtin_elementwise_fma(p, a, (f2)0.0889789874f);
+    p = __builtin_elementwise_fma(p, a, (f2)-0.2145988016f);
+    p = __builtin_elementwise_fma(p, a, (f2)1.5707963050f);
+    const f2 om = 1.0f - a;
+    f2 sq;
+    sq.x = __builtin_amdgcn_sqrtf(om.x);
+    sq.y = __builtin_amdgcn_sqrtf(om.y);
+    const f2 r = sq * p;
+    f2 b;
+    b.x = q.x < 0.0f ? 3.14159265358979f - r.x : r.x;
+    b.y = q.y < 0.0f ? 3.14159265358979f - r.y : r.y;
+    f2 lg;
+    lg.x = __builtin_amdgcn_logf(b.x);
+    lg.y = __builtin_amdgcn_logf(b.y);
+    lg = lg * 0.15f;
+    f2 bias;
+    bias.x = __builtin_amdgcn_exp2f(lg.x);
+    bias.y = __builtin_amdgcn_exp2f(lg.y);
+    sc = sc * bias;
+    ax = __builtin_elementwise_fma(sc, dx, ax);
+    ay = __builtin_elementwise_fma(sc, dy, ay);
+    az = __builtin_elementwise_fma(sc, dz, az);
+}
+
 // grid.x: target blocks of BLOCK*IPT bodies; grid.y: source slices of j_chunk bodies.
 // acc_part[slice][i - i_begin] receives the un-scaled (no G) partial sum of the slice.
 template <int LAW, int IPT>
@@ -134,10 +187,11 @@ __global__ __launch_bounds__(BLOCK) void k_allpairs(const float4* __restrict__ p
 
 // PLUMMER law with two targets per packed register pair (IPT even): same tiling, staging and
 // summation scheme as k_allpairs.
-template <int IPT>
+template <int IPT, bool BIAS = false>
 __global__ __launch_bounds__(BLOCK) void k_allpairs_plummer_pk(const float4* __restrict__ posm,
                                                                 float4* __restrict__ acc_part, int n, int i_begin,
-                                                                int i_count, int j_chunk, float eps2, int diag) {
+                                                                int i_count, int j_chunk, float eps2, int diag,
+                                                                const float4* __restrict__ vel = nullptr) {
     static_assert(IPT % 2 == 0, "packed kernel needs an even number of targets per lane");
     constexpr int H = IPT / 2;
     __shared__ float4 tile[2][TJ];
@@ -145,14 +199,24 @@ __global__ __launch_bounds__(BLOCK) void k_allpairs_plummer_pk(const float4* __r
     const int ib = i_begin + blockIdx.x * (BLOCK * IPT);
     const int i_end = i_begin + i_count;
 
-    f2 px[H], py[H], pz[H];
+    f2 px[H], py[H], pz[H], vx[H], vy[H], vz[H], vn[H];
 #pragma unroll
     for (int k = 0; k < H; ++k) {
-        float4 p0 = posm[min(ib + (2 * k) * BLOCK + tid, i_end - 1)];
-        float4 p1 = posm[min(ib + (2 * k + 1) * BLOCK + tid, i_end - 1)];
+        const int i0 = min(ib + (2 * k) * BLOCK + tid, i_end - 1), i1 = min(ib + (2 * k + 1) * BLOCK + tid, i_end - 1);
+        float4 p0 = posm[i0];
+        float4 p1 = posm[i1];
         px[k] = f2{p0.x, p1.x};
         py[k] = f2{p0.y, p1.y};
         pz[k] = f2{p0.z, p1.z};
+        if (BIAS) {
+            const float4 v0 = vel[i0], v1 = vel[i1];
+            vx[k] = f2{v0.x, v1.x};
+            vy[k] = f2{v0.y, v1.y};
+            vz[k] = f2{v0.z, v1.z};
+            // distance(vec3(0), vel), src/nbody.wgsl:75
+            vn[k] = f2{sqrtf(fmaf(v0.x, v0.x, fmaf(v0.y, v0.y, v0.z * v0.z))),
+                       sqrtf(fmaf(v1.x, v1.x, fmaf(v1.y, v1.y, v1.z * v1.z)))};
+        }
     }
     // diag: the sources are the workgroup's own BLOCK*IPT targets only (the within-superblock
     // term of the symmetric path)
@@ -185,13 +249,19 @@ __global__ __launch_bounds__(BLOCK) void k_allpairs_plummer_pk(const float4* __r
             for (int jj = 0; jj < TJ; ++jj) {
                 const float4 s = tile[buf][jj];
 #pragma unroll
-                for (int k = 0; k < H; ++k) interact_plummer_pk(px[k], py[k], pz[k], s, eps2, ax[k], ay[k], az[k]);
+                for (int k = 0; k < H; ++k) {
+                    if (BIAS) interact_bias_pk(px[k], py[k], pz[k], vx[k], vy[k], vz[k], vn[k], s, eps2, ax[k], ay[k], az[k]);
+                    else interact_plummer_pk(px[k], py[k], pz[k], s, eps2, ax[k], ay[k], az[k]);
+                }
             }
         } else {
             for (int jj = 0; jj < cnt; ++jj) {
                 const float4 s = tile[buf][jj];
 #pragma unroll
-                for (int k = 0; k < H; ++k) interact_plummer_pk(px[k], py[k], pz[k], s, eps2, ax[k], ay[k], az[k]);
+                for (int k = 0; k < H; ++k) {
+                    if (BIAS) interact_bias_pk(px[k], py[k], pz[k], vx[k], vy[k], vz[k], vn[k], s, eps2, ax[k], ay[k], az[k]);
+                    else interact_plummer_pk(px[k], py[k], pz[k], s, eps2, ax[k], ay[k], az[k]);
+                }
             }
         }
 #pragma unroll
@@ -325,8 +395,20 @@ void launch_ap_pk(nbody_ctx* ctx, const float4* posm, int slices, int j_chunk) {
                        (int)ctx->i_begin, (int)ctx->i_count, j_chunk, ctx->cfg.eps2, 0);
 }
 
+template <int IPT>
+void launch_ap_bias_pk(nbody_ctx* ctx, const float4* posm, const float4* vel, int slices, int j_chunk) {
+    dim3 grid((unsigned)((ctx->i_count + BLOCK * IPT - 1) / (BLOCK * IPT)), (unsigned)slices);
+    hipLaunchKernelGGL((k_allpairs_plummer_pk<IPT, true>), grid, dim3(BLOCK), 0, ctx->stream, posm, ctx->acc_part,
+                       (int)ctx->n, (int)ctx->i_begin, (int)ctx->i_count, j_chunk, ctx->cfg.eps2, 0, vel);
+}
+
 template <int LAW>
 void launch_ap_ipt(nbody_ctx* ctx, const float4* posm, const float4* vel, int ipt, int slices, int j_chunk) {
+    if (LAW == NBODY_LAW_WGSL_BIAS && ipt >= 2 && !env_int("NBODY_AP_NOPACK", 0)) {
+        if (ipt == 2) launch_ap_bias_pk<2>(ctx, posm, vel, slices, j_chunk);
+        else launch_ap_bias_pk<4>(ctx, posm, vel, slices, j_chunk);
+        return;
+    }
     if (LAW == NBODY_LAW_PLUMMER && ipt >= 2 && !env_int("NBODY_AP_NOPACK", 0)) {
         switch (ipt) {
             case 2: launch_ap_pk<2>(ctx, posm, slices, j_chunk); return;

@@ -11,7 +11,8 @@
 //   3. k_prefix      per sorted body: common-prefix depth with both neighbours => the range of
 //                    levels [lo, top] at which it is the first body of an existing cell
 //   4. row scans     breadth-first numbering: node id = level_start[d] + rank of the cell in d
-//   5. k_emit        writes the nodes, links each into its parent's child slot (octant order)
+//   5. k_emit        writes the nodes; children are consecutive (octant order), so a node only
+//                    records where they start
 //   6. k_leaflist    depth-cap cells: sequential prefix aggregates in index order (literal
 //                    reference arithmetic, src/octree_maxdepth.rs:91-136)
 //   7. k_aggregate   bottom-up, one launch per level: mass, centre of mass, bounds, range
@@ -22,7 +23,7 @@
 // (node, lane mask) entries in LDS.  A node is opened if any lane needs it; lanes that accepted
 // an ancestor are masked out of its subtree, so each lane sees exactly the node sequence of the
 // reference's private depth-first stack (children pushed ascending, popped highest first).
-// Node records are 64 bytes and are fetched with wave-uniform (scalar) loads.
+// Node records are 32 bytes and are fetched with wave-uniform (scalar) loads.
 #include "ctx.h"
 #include "laws.h"
 #include <algorithm>
@@ -35,16 +36,17 @@ constexpr int NCNT = 18;       // level counters 0..16 + leaf-list members
 constexpr int LIST_ROW = 17;
 constexpr uint32_t NO_NODE = 0xffffffffu;
 
-// Traversal record (64 B): one s_load_dwordx16 per visit.
-struct WNode {
+// Node record (32 B): written by the build, fetched by the traversal with one s_load_dwordx8.
+// Breadth-first numbering makes the children of a node (octant order) and the members of a leaf
+// list consecutive: [first, first + count).
+struct QNode {
     float cx, cy, cz, mass;
     float range;
     uint32_t type;
-    uint32_t depth;
-    uint32_t head;  // sorted rank of the first body of the cell (build bookkeeping)
-    uint32_t child[8];
+    uint32_t first;
+    uint32_t count;
 };
-static_assert(sizeof(WNode) == 64, "walk node layout");
+static_assert(sizeof(QNode) == 32, "node record layout");
 
 }  // namespace
 
@@ -69,10 +71,10 @@ struct Octree {
     uint32_t* lvl_start = nullptr;  // [NCNT+1]
     uint32_t h_lvl_start[NCNT + 1] = {0};
     // nodes
-    WNode* nodes = nullptr;
-    struct QNodeOpaque* walk = nullptr;  // QNode[cap_nodes]
-    float4* bmin = nullptr;
+    QNode* nodes = nullptr;
+    float4* bmin = nullptr;          // bounding box of the bodies below each node
     float4* bmax = nullptr;
+    uint32_t* node_head = nullptr;   // sorted rank of the first body of each node's cell
     uint64_t cap_nodes = 0;
     uint64_t n_nodes = 0;
     bool have_tree = false;
@@ -80,6 +82,7 @@ struct Octree {
     // export buffer
     nbody_octree_node* export_buf = nullptr;
     uint64_t export_cap = 0;
+    bool export_is_upload = false;  // export_buf holds the (renumbered) uploaded tree
     // walk
     uint32_t* shard_order = nullptr;  // sorted ranks' body indices restricted to the shard
     uint64_t* walk_counters = nullptr;  // [8]
@@ -294,25 +297,22 @@ __global__ __launch_bounds__(256) void k_emit(const uint64_t* __restrict__ keys,
                                               const float4* __restrict__ posm, uint32_t n, int D,
                                               const uint8_t* __restrict__ lo, const uint8_t* __restrict__ top,
                                               const uint8_t* __restrict__ flags, const uint32_t* __restrict__ blk,
-                                              uint32_t nb, const uint32_t* __restrict__ lvl_start, WNode* __restrict__ nodes,
+                                              uint32_t nb, const uint32_t* __restrict__ lvl_start, QNode* __restrict__ nodes,
                                               float4* __restrict__ bmin, float4* __restrict__ bmax,
-                                              uint32_t* __restrict__ body_node, uint32_t cap_nodes,
-                                              uint32_t* __restrict__ err_flag) {
+                                              uint32_t* __restrict__ node_head, uint32_t* __restrict__ body_node,
+                                              uint32_t cap_nodes, uint32_t* __restrict__ err_flag) {
     __shared__ uint32_t wtot[NCNT][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t i = blockIdx.x * 256 + tid;
     const bool valid = i < n;
     int l = 1, t = 0;
     uint32_t f = 0;
-    uint64_t key = 0;
     if (valid) {
         l = lo[i];
         t = top[i];
         f = flags[i];
-        key = keys[i];
     }
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const unsigned long long le = lt | (1ull << lane);
 #pragma unroll
     for (int d = 0; d < NCNT; ++d) {
         const bool has = valid && ((d < LIST_ROW) ? (l <= d && d <= t) : (f & 1u));
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void k_emit(const uint64_t* __restrict__ keys,
         if (lane == 0) wtot[d][wave] = (uint32_t)__popcll(b);
     }
     __syncthreads();
-    // rank among leaf-list members (for the first member of a list)
+    // rank of this body among the leaf-list members
     uint32_t list_first = 0;
     {
         const unsigned long long b = __ballot(valid && (f & 1u));
@@ -331,14 +331,18 @@ __global__ __launch_bounds__(256) void k_emit(const uint64_t* __restrict__ keys,
     float4 p = make_float4(0, 0, 0, 0);
     if (valid && l <= t) p = posm[idx[i]];
     if (valid && l > t) body_node[i] = NO_NODE;
-    uint32_t prev_incl = 0;
+    // Node id at level d = level_start[d] + rank of the body among the level-d heads.  That same
+    // rank, taken by a body that heads a cell at level d-1, is where that cell's children start
+    // (and for a childless cell it makes the next cell's start minus its own come out as 0).
+    uint32_t pend = NO_NODE;
     for (int d = 0; d <= D; ++d) {
         const bool has = valid && l <= d && d <= t;
         const unsigned long long b = __ballot(has);
         uint32_t base = lvl_start[d] + blk[(size_t)d * nb + blockIdx.x];
         for (int w = 0; w < wave; ++w) base += wtot[d][w];
         const uint32_t id = base + (uint32_t)__popcll(b & lt);
-        const uint32_t incl = base + (uint32_t)__popcll(b & le);
+        if (pend != NO_NODE) nodes[pend].first = id;
+        pend = NO_NODE;
         if (has) {
             if (id >= cap_nodes) {
                 *err_flag = 1;
@@ -347,31 +351,22 @@ __global__ __launch_bounds__(256) void k_emit(const uint64_t* __restrict__ keys,
                 if (d < t) type = NBODY_NODE_INTERIOR;
                 else if (f & 2u) type = NBODY_NODE_LEAFLIST;  // d == t == D, first of >= 2 bodies
                 else type = NBODY_NODE_LEAFBODY;
-                WNode& nd = nodes[id];
+                QNode nd;
+                nd.cx = p.x; nd.cy = p.y; nd.cz = p.z; nd.mass = p.w;  // src/octree_maxdepth.rs:75-86 for a LEAFBODY;
+                nd.range = 0.0f;                                       // aggregates are filled in later otherwise
                 nd.type = type;
-                nd.depth = (uint32_t)d;
-                nd.head = i;
-                if (type == NBODY_NODE_LEAFBODY) {  // src/octree_maxdepth.rs:75-86
-                    nd.cx = p.x;
-                    nd.cy = p.y;
-                    nd.cz = p.z;
-                    nd.mass = p.w;
-                    nd.range = 0.0f;
-                    bmin[id] = make_float4(p.x, p.y, p.z, 0.0f);
-                    bmax[id] = make_float4(p.x, p.y, p.z, 0.0f);
-                } else if (type == NBODY_NODE_LEAFLIST) {
-                    nd.child[0] = list_first;  // child[1] (the count) is written by k_leaflist
-                }
-                if (d > 0) {
-                    const uint32_t parent = prev_incl - 1;  // last cell of level d-1 starting at or before i
-                    const uint32_t oct = (uint32_t)(key >> (3 * (D - d))) & 7u;
-                    nodes[parent].child[oct] = id;
-                }
+                nd.first = 0;
+                nd.count = 0;
+                nodes[id] = nd;
+                bmin[id] = make_float4(p.x, p.y, p.z, 0.0f);
+                bmax[id] = make_float4(p.x, p.y, p.z, 0.0f);
+                node_head[id] = i;
                 if (d == t) body_node[i] = id;
+                pend = id;
             }
         }
-        prev_incl = incl;
     }
+    if (pend != NO_NODE) nodes[pend].first = list_first;  // depth-cap cell: its list members (if any)
 }
 
 // ---- 6. depth-cap cells -------------------------------------------------------------------
@@ -379,28 +374,30 @@ __global__ __launch_bounds__(256) void k_emit(const uint64_t* __restrict__ keys,
 // order, and the list members it creates (src/octree_maxdepth.rs:91-136).
 __global__ void k_leaflist(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idx,
                            const float4* __restrict__ posm, uint32_t n, int list_mode, const uint8_t* __restrict__ flags,
-                           const uint32_t* __restrict__ body_node, WNode* __restrict__ nodes, float4* __restrict__ bmin,
-                           float4* __restrict__ bmax, uint32_t cap_nodes, uint32_t D) {
+                           const uint32_t* __restrict__ body_node, QNode* __restrict__ nodes, float4* __restrict__ bmin,
+                           float4* __restrict__ bmax, uint32_t* __restrict__ node_head, uint32_t cap_nodes) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || !(flags[i] & 2u)) return;
     const uint32_t id = body_node[i];
     if (id >= cap_nodes) return;
-    WNode& nd = nodes[id];
+    QNode nd = nodes[id];
     const uint64_t key = keys[i];
-    uint32_t member = nd.child[0];
+    uint32_t member = nd.first;
     uint32_t count = 0;
     float4 a = posm[idx[i]];  // aggregate: xyz = centre of mass, w = mass
     float mnx = a.x, mny = a.y, mnz = a.z, mxx = a.x, mxy = a.y, mxz = a.z;
     auto put = [&](float4 q) {
         if (member < cap_nodes) {
-            WNode& c = nodes[member];
+            QNode c;
             c.cx = q.x; c.cy = q.y; c.cz = q.z; c.mass = q.w;
             c.range = 0.0f;
             c.type = NBODY_NODE_LEAFBODY;
-            c.depth = D;  // src/octree_maxdepth.rs:132 inserts the member with depth 0; recorded as the cell's
-            c.head = i;
+            c.first = 0;
+            c.count = 0;
+            nodes[member] = c;
             bmin[member] = make_float4(q.x, q.y, q.z, 0.0f);
             bmax[member] = make_float4(q.x, q.y, q.z, 0.0f);
+            node_head[member] = i;
         }
         ++member;
         ++count;
@@ -420,26 +417,27 @@ __global__ void k_leaflist(const uint64_t* __restrict__ keys, const uint32_t* __
     }
     nd.cx = a.x; nd.cy = a.y; nd.cz = a.z; nd.mass = a.w;
     nd.range = fmaxf(mxx - mnx, fmaxf(mxy - mny, mxz - mnz));
-    nd.child[1] = count;
+    nd.count = count;
+    nodes[id] = nd;
     bmin[id] = make_float4(mnx, mny, mnz, 0.0f);
     bmax[id] = make_float4(mxx, mxy, mxz, 0.0f);
 }
 
 // ---- 7. aggregates ------------------------------------------------------------------------
-__global__ void k_aggregate(WNode* __restrict__ nodes, float4* __restrict__ bmin, float4* __restrict__ bmax,
-                            uint32_t first, uint32_t count) {
+// One level: nodes [first_id, first_id + count).  The children of a node end where the next
+// node's begin (`child_end` for the last node of the level).
+__global__ void k_aggregate(QNode* __restrict__ nodes, float4* __restrict__ bmin, float4* __restrict__ bmax,
+                            uint32_t first_id, uint32_t count, uint32_t child_end) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= count) return;
-    const uint32_t id = first + r;
-    WNode& nd = nodes[id];
+    const uint32_t id = first_id + r;
+    QNode nd = nodes[id];
     if (nd.type != NBODY_NODE_INTERIOR) return;
+    const uint32_t c0 = nd.first, c1 = (r + 1 < count) ? nodes[id + 1].first : child_end;
     float M = 0.0f, wx = 0.0f, wy = 0.0f, wz = 0.0f;
     float mnx = INFINITY, mny = INFINITY, mnz = INFINITY, mxx = -INFINITY, mxy = -INFINITY, mxz = -INFINITY;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const uint32_t c = nd.child[k];
-        if (c == 0) continue;
-        const WNode& ch = nodes[c];
+    for (uint32_t c = c0; c < c1; ++c) {
+        const QNode ch = nodes[c];
         M += ch.mass;
         wx += ch.cx * ch.mass;
         wy += ch.cy * ch.mass;
@@ -453,43 +451,70 @@ __global__ void k_aggregate(WNode* __restrict__ nodes, float4* __restrict__ bmin
     nd.cy = wy / M;
     nd.cz = wz / M;
     nd.range = fmaxf(mxx - mnx, fmaxf(mxy - mny, mxz - mnz));  // src/octree_maxdepth.rs:101
+    nd.count = c1 - c0;
+    nodes[id] = nd;
     bmin[id] = make_float4(mnx, mny, mnz, 0.0f);
     bmax[id] = make_float4(mxx, mxy, mxz, 0.0f);
 }
 
 // ---- export / import (96-byte reference layout) ---------------------------------------------
-__global__ void k_export(const WNode* __restrict__ nodes, const float4* __restrict__ bmin, const float4* __restrict__ bmax,
-                         uint32_t count, nbody_octree_node* __restrict__ out) {
+__global__ void k_export(const QNode* __restrict__ nodes, const float4* __restrict__ bmin, const float4* __restrict__ bmax,
+                         const uint32_t* __restrict__ node_head, const uint64_t* __restrict__ keys,
+                         const uint32_t* __restrict__ lvl_start, int D, uint32_t count, nbody_octree_node* __restrict__ out) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= count) return;
-    const WNode nd = nodes[id];
+    const QNode nd = nodes[id];
     const float4 lo = bmin[id], hi = bmax[id];
+    int depth = 0;
+    while (depth < D && id >= lvl_start[depth + 1]) ++depth;  // list members land on D, the depth of their cell
     nbody_octree_node o;
     o.center_of_mass[0] = nd.cx; o.center_of_mass[1] = nd.cy; o.center_of_mass[2] = nd.cz; o._pad0 = 0.0f;
     o.pos_min[0] = lo.x; o.pos_min[1] = lo.y; o.pos_min[2] = lo.z; o._pad1 = 0.0f;
     o.pos_max[0] = hi.x; o.pos_max[1] = hi.y; o.pos_max[2] = hi.z;
     o.range = nd.range;
     o.total_mass = nd.mass;
-    for (int k = 0; k < 8; ++k) o.child_indices[k] = nd.child[k];
+    for (int k = 0; k < 8; ++k) o.child_indices[k] = 0;
+    if (nd.type == NBODY_NODE_INTERIOR) {
+        // the octant of a child is the digit of its bodies' keys at the child's level
+        for (uint32_t c = nd.first; c < nd.first + nd.count; ++c)
+            o.child_indices[(uint32_t)(keys[node_head[c]] >> (3 * (D - depth - 1))) & 7u] = c;
+    } else if (nd.type == NBODY_NODE_LEAFLIST) {
+        o.child_indices[0] = nd.first;
+        o.child_indices[1] = nd.count;
+    }
     o.node_type = nd.type;
-    o.depth = nd.depth;
+    o.depth = (uint32_t)depth;
     o._pad2 = 0;
     out[id] = o;
 }
 
-__global__ void k_import(const nbody_octree_node* __restrict__ in, uint32_t count, WNode* __restrict__ nodes,
-                         float4* __restrict__ bmin, float4* __restrict__ bmax) {
+// Uploaded trees arrive renumbered breadth-first by the host: children consecutive in octant order.
+__global__ void k_import(const nbody_octree_node* __restrict__ in, uint32_t count, QNode* __restrict__ nodes,
+                         float4* __restrict__ bmin, float4* __restrict__ bmax, uint32_t* __restrict__ err_flag) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= count) return;
     const nbody_octree_node o = in[id];
-    WNode nd;
+    QNode nd;
     nd.cx = o.center_of_mass[0]; nd.cy = o.center_of_mass[1]; nd.cz = o.center_of_mass[2];
     nd.mass = o.total_mass;
     nd.range = o.range;
     nd.type = o.node_type;
-    nd.depth = o.depth;
-    nd.head = 0;
-    for (int k = 0; k < 8; ++k) nd.child[k] = o.child_indices[k];
+    nd.first = 0;
+    nd.count = 0;
+    if (o.node_type == NBODY_NODE_INTERIOR) {
+        uint32_t last = 0;
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t c = o.child_indices[k];
+            if (c == 0) continue;
+            if (nd.count == 0) nd.first = c;
+            else if (c != last + 1) *err_flag = 3;
+            last = c;
+            ++nd.count;
+        }
+    } else if (o.node_type == NBODY_NODE_LEAFLIST) {
+        nd.first = o.child_indices[0];
+        nd.count = max(o.child_indices[1], 1u);  // src/nbodybh.wgsl:139-146 is a do-while: at least one member
+    }
     nodes[id] = nd;
     bmin[id] = make_float4(o.pos_min[0], o.pos_min[1], o.pos_min[2], 0.0f);
     bmax[id] = make_float4(o.pos_max[0], o.pos_max[1], o.pos_max[2], 0.0f);
@@ -529,46 +554,9 @@ __global__ __launch_bounds__(1024) void k_compact_order(const uint32_t* __restri
 }
 
 // ---- traversal ----------------------------------------------------------------------------
-// Walk record (32 B, one s_load_dwordx8): the children of a node are CONTIGUOUS (breadth-first
-// numbering; uploaded trees are renumbered on the host), so a node that must be opened is pushed
-// as (first child, count, lane mask) and its children are fetched together when it is popped.
-struct QNode {
-    float cx, cy, cz, mass;
-    float range;
-    uint32_t type;
-    uint32_t first;  // first child (INTERIOR) or first list member (LEAFLIST)
-    uint32_t count;  // children / list members
-};
-static_assert(sizeof(QNode) == 32, "walk record layout");
-
-__global__ void k_make_walk(const WNode* __restrict__ nodes, uint32_t count, QNode* __restrict__ q,
-                            uint32_t* __restrict__ err_flag) {
-    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= count) return;
-    const WNode nd = nodes[id];
-    QNode o;
-    o.cx = nd.cx; o.cy = nd.cy; o.cz = nd.cz; o.mass = nd.mass;
-    o.range = nd.range;
-    o.type = nd.type;
-    o.first = 0;
-    o.count = 0;
-    if (nd.type == NBODY_NODE_INTERIOR) {
-        uint32_t last = 0;
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t c = nd.child[k];
-            if (c == 0) continue;
-            if (o.count == 0) o.first = c;
-            else if (c != last + 1) *err_flag = 3;  // children must be consecutive in octant order
-            last = c;
-            ++o.count;
-        }
-    } else if (nd.type == NBODY_NODE_LEAFLIST) {
-        o.first = nd.child[0];
-        o.count = max(nd.child[1], 1u);  // src/nbodybh.wgsl:139-146 is a do-while: at least one member
-    }
-    q[id] = o;
-}
-
+// The children of a node are CONTIGUOUS (breadth-first numbering; uploaded trees are renumbered on
+// the host), so a node that must be opened is pushed as (first child, count, lane mask) and its
+// children are fetched together when it is popped.
 constexpr int WALK_STACK = 160;  // >= 8 pushes per level x 17 levels + root
 
 template <int LAW, bool COUNT>
@@ -682,15 +670,15 @@ int ensure_nodes(nbody_ctx* ctx, Octree* T, uint64_t need) {
     uint64_t cap = std::max<uint64_t>(need + need / 4 + 1024, 2 * T->n + 1024);
     if (cap > 0xfffffff0ull) return nb_fail(ctx, NBODY_ERR_CAPACITY, "octree needs more than 2^32 nodes");
     if (T->nodes) NB_HIP(ctx, hipFree(T->nodes));
-    if (T->walk) NB_HIP(ctx, hipFree(T->walk));
-    T->walk = nullptr;
+    if (T->node_head) NB_HIP(ctx, hipFree(T->node_head));
+    T->node_head = nullptr;
     if (T->bmin) NB_HIP(ctx, hipFree(T->bmin));
     if (T->bmax) NB_HIP(ctx, hipFree(T->bmax));
     T->nodes = nullptr;
     T->bmin = T->bmax = nullptr;
     T->cap_nodes = 0;
-    NB_HIP(ctx, hipMalloc(&T->nodes, cap * sizeof(WNode)));
-    NB_HIP(ctx, hipMalloc(&T->walk, cap * sizeof(QNode)));
+    NB_HIP(ctx, hipMalloc(&T->nodes, cap * sizeof(QNode)));
+    NB_HIP(ctx, hipMalloc(&T->node_head, cap * sizeof(uint32_t)));
     NB_HIP(ctx, hipMalloc(&T->bmin, cap * sizeof(float4)));
     NB_HIP(ctx, hipMalloc(&T->bmax, cap * sizeof(float4)));
     T->cap_nodes = cap;
@@ -716,11 +704,11 @@ void launch_walk(nbody_ctx* ctx, Octree* T, const uint32_t* order, uint32_t m, c
                  float4* acc_out) {
     dim3 grid((m + 255) / 256);
     if (ctx->counting)
-        hipLaunchKernelGGL((k_walk<LAW, true>), grid, dim3(256), 0, ctx->stream, (const QNode*)T->walk, order, m, (uint32_t)ctx->i_begin,
+        hipLaunchKernelGGL((k_walk<LAW, true>), grid, dim3(256), 0, ctx->stream, T->nodes, order, m, (uint32_t)ctx->i_begin,
                            posm, vel, acc_out, ctx->cfg.G, ctx->cfg.eps2, ctx->cfg.theta,
                            (unsigned long long*)T->walk_counters, T->err_flag);
     else
-        hipLaunchKernelGGL((k_walk<LAW, false>), grid, dim3(256), 0, ctx->stream, (const QNode*)T->walk, order, m, (uint32_t)ctx->i_begin,
+        hipLaunchKernelGGL((k_walk<LAW, false>), grid, dim3(256), 0, ctx->stream, T->nodes, order, m, (uint32_t)ctx->i_begin,
                            posm, vel, acc_out, ctx->cfg.G, ctx->cfg.eps2, ctx->cfg.theta,
                            (unsigned long long*)T->walk_counters, T->err_flag);
 }
@@ -764,7 +752,7 @@ void nb_tree_destroy(nbody_ctx* ctx) {
         if (T->idx[s]) hipFree(T->idx[s]);
     }
     void* ptrs[] = {T->lo, T->top, T->flags, T->body_node, T->rs_counts, T->row_total, T->row_base, T->blk,
-                    T->lvl_total, T->lvl_start, T->nodes, T->walk, T->bmin, T->bmax, T->export_buf, T->shard_order,
+                    T->lvl_total, T->lvl_start, T->nodes, T->node_head, T->bmin, T->bmax, T->export_buf, T->shard_order,
                     T->walk_counters, T->err_flag};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -803,27 +791,27 @@ int nb_tree_build(nbody_ctx* ctx, const float4* posm_in) {
     int r = ensure_nodes(ctx, T, total);
     if (r) return r;
     T->n_nodes = total;
-    NB_HIP(ctx, hipMemsetAsync(T->nodes, 0, total * sizeof(WNode), st));
     hipLaunchKernelGGL(k_emit, dim3(T->pf_nb), dim3(256), 0, st, T->keys[cur], T->idx[cur], posm_in, n, D, T->lo, T->top,
-                       T->flags, T->blk, T->pf_nb, T->lvl_start, T->nodes, T->bmin, T->bmax, T->body_node,
+                       T->flags, T->blk, T->pf_nb, T->lvl_start, T->nodes, T->bmin, T->bmax, T->node_head, T->body_node,
                        (uint32_t)T->cap_nodes, T->err_flag);
     NB_HIP(ctx, hipGetLastError());
     if (T->h_lvl_start[LIST_ROW + 1] > T->h_lvl_start[LIST_ROW] || T->h_lvl_start[D + 1] > T->h_lvl_start[D]) {
         hipLaunchKernelGGL(k_leaflist, dim3((n + 255) / 256), dim3(256), 0, st, T->keys[cur], T->idx[cur], posm_in, n,
-                           ctx->cfg.leaflist_mode, T->flags, T->body_node, T->nodes, T->bmin, T->bmax,
-                           (uint32_t)T->cap_nodes, (uint32_t)D);
+                           ctx->cfg.leaflist_mode, T->flags, T->body_node, T->nodes, T->bmin, T->bmax, T->node_head,
+                           (uint32_t)T->cap_nodes);
         NB_HIP(ctx, hipGetLastError());
     }
     for (int d = D - 1; d >= 0; --d) {
         const uint32_t first = T->h_lvl_start[d], count = T->h_lvl_start[d + 1] - first;
         if (!count) continue;
-        hipLaunchKernelGGL(k_aggregate, dim3((count + 255) / 256), dim3(256), 0, st, T->nodes, T->bmin, T->bmax, first, count);
+        // the children of level d are the nodes of level d + 1
+        hipLaunchKernelGGL(k_aggregate, dim3((count + 255) / 256), dim3(256), 0, st, T->nodes, T->bmin, T->bmax, first, count,
+                           T->h_lvl_start[d + 2]);
     }
-    hipLaunchKernelGGL(k_make_walk, dim3(((uint32_t)total + 255) / 256), dim3(256), 0, st, T->nodes, (uint32_t)total,
-                       (QNode*)T->walk, T->err_flag);
     NB_HIP(ctx, hipGetLastError());
     T->have_tree = true;
     T->built = true;
+    T->export_is_upload = false;
     ctx->counters.octree_nodes = total;
     return NBODY_OK;
 }
@@ -882,6 +870,7 @@ int nb_tree_device_nodes(nbody_ctx* ctx, void** ptr, size_t* bytes) {
     Octree* T = ctx->tree;
     if (!T->have_tree) return nb_fail(ctx, NBODY_ERR_STATE, "no octree");
     if (T->export_cap < T->n_nodes) {
+        if (T->export_is_upload) return nb_fail(ctx, NBODY_ERR_STATE, "octree export buffer lost");
         if (T->export_buf) NB_HIP(ctx, hipFree(T->export_buf));
         T->export_buf = nullptr;
         T->export_cap = 0;
@@ -889,9 +878,11 @@ int nb_tree_device_nodes(nbody_ctx* ctx, void** ptr, size_t* bytes) {
         T->export_cap = T->cap_nodes;
     }
     const uint32_t cnt = (uint32_t)T->n_nodes;
-    hipLaunchKernelGGL(k_export, dim3((cnt + 255) / 256), dim3(256), 0, ctx->stream, T->nodes, T->bmin, T->bmax, cnt,
-                       T->export_buf);
-    NB_HIP(ctx, hipGetLastError());
+    if (!T->export_is_upload) {  // an uploaded tree is kept as it came (renumbered); a built one is exported
+        hipLaunchKernelGGL(k_export, dim3((cnt + 255) / 256), dim3(256), 0, ctx->stream, T->nodes, T->bmin, T->bmax,
+                           T->node_head, T->keys[T->sorted], T->lvl_start, (int)T->D, cnt, T->export_buf);
+        NB_HIP(ctx, hipGetLastError());
+    }
     *ptr = T->export_buf;
     if (bytes) *bytes = T->n_nodes * sizeof(nbody_octree_node);
     return NBODY_OK;
@@ -954,13 +945,14 @@ int nb_tree_upload(nbody_ctx* ctx, const nbody_octree_node* host_nodes, uint64_t
     }
     NB_HIP(ctx, hipMemcpyAsync(T->export_buf, renum.data(), kept * sizeof(nbody_octree_node), hipMemcpyHostToDevice, ctx->stream));
     const uint32_t cnt = (uint32_t)kept;
-    hipLaunchKernelGGL(k_import, dim3((cnt + 255) / 256), dim3(256), 0, ctx->stream, T->export_buf, cnt, T->nodes, T->bmin, T->bmax);
-    hipLaunchKernelGGL(k_make_walk, dim3((cnt + 255) / 256), dim3(256), 0, ctx->stream, T->nodes, cnt, (QNode*)T->walk, T->err_flag);
+    hipLaunchKernelGGL(k_import, dim3((cnt + 255) / 256), dim3(256), 0, ctx->stream, T->export_buf, cnt, T->nodes, T->bmin,
+                       T->bmax, T->err_flag);
     NB_HIP(ctx, hipGetLastError());
     NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     T->n_nodes = kept;
     T->have_tree = true;
     T->built = false;  // no sorted order for this tree: targets are walked in index order
+    T->export_is_upload = true;
     ctx->counters.octree_nodes = kept;
     return check_err_flag(ctx, T, "nbody_upload_octree");
 }

@@ -84,6 +84,7 @@ struct Octree {
     uint64_t export_cap = 0;
     bool export_is_upload = false;  // export_buf holds the (renumbered) uploaded tree
     // walk
+    uint32_t* shard_blk = nullptr;   // per-workgroup counts of the compaction below, then their scan
     uint32_t* shard_order = nullptr;  // sorted ranks' body indices restricted to the shard
     uint64_t* walk_counters = nullptr;  // [8]
     uint32_t* err_flag = nullptr;
@@ -522,15 +523,36 @@ __global__ void k_import(const nbody_octree_node* __restrict__ in, uint32_t coun
 
 // Body indices of the sorted order restricted to [i_begin, i_end): stable compaction, one
 // workgroup (the shard lists are rebuilt once per step; n / 1024 trips).
-__global__ __launch_bounds__(1024) void k_compact_order(const uint32_t* __restrict__ idx, uint32_t n, uint32_t i_begin,
-                                                         uint32_t i_end, uint32_t* __restrict__ out) {
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t carry_s;
+constexpr int CO_ITEMS = 16, CO_TILE = 256 * CO_ITEMS;
+
+__global__ __launch_bounds__(256) void k_compact_count(const uint32_t* __restrict__ idx, uint32_t n, uint32_t i_begin,
+                                                       uint32_t i_end, uint32_t* __restrict__ blk) {
+    __shared__ uint32_t wsum[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) carry_s = 0;
+    uint32_t c = 0;
+    for (int it = 0; it < CO_ITEMS; ++it) {
+        const uint32_t r = blockIdx.x * CO_TILE + it * 256 + tid;
+        if (r < n) {
+            const uint32_t b = idx[r];
+            c += (b >= i_begin && b < i_end) ? 1u : 0u;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if (lane == 0) wsum[wave] = c;
     __syncthreads();
-    for (uint32_t base = 0; base < n; base += 1024) {
-        const uint32_t r = base + tid;
+    if (tid == 0) blk[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// blk holds the exclusive scan of the per-workgroup counts; the sorted order is kept.
+__global__ __launch_bounds__(256) void k_compact_scatter(const uint32_t* __restrict__ idx, uint32_t n, uint32_t i_begin,
+                                                         uint32_t i_end, const uint32_t* __restrict__ blk,
+                                                         uint32_t* __restrict__ out, uint32_t cap) {
+    __shared__ uint32_t wsum[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t run = blk[blockIdx.x];
+    for (int it = 0; it < CO_ITEMS; ++it) {
+        const uint32_t r = blockIdx.x * CO_TILE + it * 256 + tid;
         uint32_t b = 0;
         bool keep = false;
         if (r < n) {
@@ -538,18 +560,13 @@ __global__ __launch_bounds__(1024) void k_compact_order(const uint32_t* __restri
             keep = b >= i_begin && b < i_end;
         }
         const unsigned long long m = __ballot(keep);
-        if (lane == 0) wsum[wave] = (uint32_t)__popcll(m);
-        __syncthreads();
-        uint32_t off = carry_s;
-        for (int w = 0; w < wave; ++w) off += wsum[w];
-        if (keep) out[off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = b;
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t tot = 0;
-            for (int w = 0; w < 16; ++w) tot += wsum[w];
-            carry_s += tot;
-        }
-        __syncthreads();
+        if (lane == 0) wsum[it & 1][wave] = (uint32_t)__popcll(m);
+        __syncthreads();  // the other half of wsum is what the previous round may still be reading
+        uint32_t off = run;
+        for (int w = 0; w < wave; ++w) off += wsum[it & 1][w];
+        off += (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (keep && off < cap) out[off] = b;
+        run += wsum[it & 1][0] + wsum[it & 1][1] + wsum[it & 1][2] + wsum[it & 1][3];
     }
 }
 
@@ -740,7 +757,10 @@ int nb_tree_create(nbody_ctx* ctx) {
     NB_HIP(ctx, hipMalloc(&T->walk_counters, 8 * sizeof(uint64_t)));
     NB_HIP(ctx, hipMalloc(&T->err_flag, sizeof(uint32_t)));
     NB_HIP(ctx, hipMemsetAsync(T->err_flag, 0, sizeof(uint32_t), ctx->stream));
-    if (ctx->i_count < ctx->n) NB_HIP(ctx, hipMalloc(&T->shard_order, ctx->i_count * sizeof(uint32_t)));
+    if (ctx->i_count < ctx->n) {
+        NB_HIP(ctx, hipMalloc(&T->shard_order, ctx->i_count * sizeof(uint32_t)));
+        NB_HIP(ctx, hipMalloc(&T->shard_blk, ((n + CO_TILE - 1) / CO_TILE + 1) * sizeof(uint32_t)));
+    }
     return ensure_nodes(ctx, T, 2 * n + 1024);
 }
 
@@ -752,7 +772,7 @@ void nb_tree_destroy(nbody_ctx* ctx) {
         if (T->idx[s]) hipFree(T->idx[s]);
     }
     void* ptrs[] = {T->lo, T->top, T->flags, T->body_node, T->rs_counts, T->row_total, T->row_base, T->blk,
-                    T->lvl_total, T->lvl_start, T->nodes, T->node_head, T->bmin, T->bmax, T->export_buf, T->shard_order,
+                    T->lvl_total, T->lvl_start, T->nodes, T->node_head, T->bmin, T->bmax, T->export_buf, T->shard_order, T->shard_blk,
                     T->walk_counters, T->err_flag};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -826,8 +846,12 @@ int nb_tree_walk(nbody_ctx* ctx, const float4* posm_in, const float4* vel_in, fl
         if (ctx->i_count == ctx->n) {
             order = T->idx[T->sorted];
         } else {
-            hipLaunchKernelGGL(k_compact_order, dim3(1), dim3(1024), 0, st, T->idx[T->sorted], (uint32_t)T->n,
-                               (uint32_t)ctx->i_begin, (uint32_t)(ctx->i_begin + ctx->i_count), T->shard_order);
+            const uint32_t nb = ((uint32_t)T->n + CO_TILE - 1) / CO_TILE;
+            const uint32_t b0 = (uint32_t)ctx->i_begin, b1 = (uint32_t)(ctx->i_begin + ctx->i_count);
+            hipLaunchKernelGGL(k_compact_count, dim3(nb), dim3(256), 0, st, T->idx[T->sorted], (uint32_t)T->n, b0, b1, T->shard_blk);
+            hipLaunchKernelGGL(k_rowscan, dim3(1), dim3(256), 0, st, T->shard_blk, nb, T->shard_blk + nb);
+            hipLaunchKernelGGL(k_compact_scatter, dim3(nb), dim3(256), 0, st, T->idx[T->sorted], (uint32_t)T->n, b0, b1,
+                               T->shard_blk, T->shard_order, m);
             order = T->shard_order;
         }
     }

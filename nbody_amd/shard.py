@@ -16,6 +16,8 @@ out over the ranks, each rank produces its contribution to every body's accelera
 (16 bytes per body), the ranks all-reduce that buffer, integrate their own targets and
 all-gather the positions as before: two collectives per step.
 """
+import contextlib
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -48,8 +50,12 @@ class HipShardBackend:
         self._buf_partial = BUF_ACC_PARTIAL
         self.pair_sharding = (cfg.get("law") == LAW_PLUMMER and cfg.get("integrator", INT_WGSL_VERLET) == INT_WGSL_VERLET
                               and n >= self.PAIR_SHARD_MIN_N)
-        stream = torch.cuda.current_stream().cuda_stream
-        self.sim = NBodySim(n, shard_begin=begin, shard_count=count, device=device_index, stream=stream, **cfg)
+        # One explicit stream carries the library's kernels AND the collectives' stream
+        # dependencies.  (A null stream handle would not do: the library takes it as "create a
+        # stream of your own", which torch then knows nothing about.)
+        self.torch_stream = torch.cuda.Stream(device=device_index)
+        self.sim = NBodySim(n, shard_begin=begin, shard_count=count, device=device_index,
+                            stream=self.torch_stream.cuda_stream, **cfg)
         self.n = n
         self._views = {}
 
@@ -94,20 +100,51 @@ class ShardedSim:
         self.begin, self.count = shard_range(n, self.rank, self.world)
         self._nccl = dist.get_backend(group) == "nccl" if dist.is_initialized() else False
 
+    def _stream(self):
+        """Collectives and tensor ops must be enqueued on the stream the backend computes on."""
+        s = getattr(self.backend, "torch_stream", None)
+        return torch.cuda.stream(s) if s is not None else contextlib.nullcontext()
+
     def exchange(self):
         """All-gather the current positions: every rank's own range reaches all the others."""
         if self.world == 1:
             return
+        with self._stream():
+            self._exchange()
+
+    def _exchange(self):
         full = self.backend.posm()
         if self.n % self.world == 0:
             # a private copy of the own range (16 B/body): input and output never alias
             own = full[self.begin:self.begin + self.count].clone()
-            dist.all_gather_into_tensor(full, own, group=self.group)
+            if full.is_cuda and not self._nccl:
+                # device tensors over a host-only backend (tests: gloo): stage through the host
+                host = torch.empty(full.shape, dtype=full.dtype)
+                dist.all_gather_into_tensor(host, own.cpu(), group=self.group)
+                full.copy_(host)
+            else:
+                dist.all_gather_into_tensor(full, own, group=self.group)
         else:
             for r in range(self.world):
                 b, c = shard_range(self.n, r, self.world)
-                dist.broadcast(full[b:b + c], src=dist.get_global_rank(self.group, r) if self.group else r,
-                               group=self.group)
+                src = dist.get_global_rank(self.group, r) if self.group else r
+                part = full[b:b + c]
+                if full.is_cuda and not self._nccl:
+                    host = part.cpu()
+                    dist.broadcast(host, src=src, group=self.group)
+                    if r != self.rank:
+                        part.copy_(host)
+                else:
+                    dist.broadcast(part, src=src, group=self.group)
+
+    def _sum_partials(self):
+        part = self.backend.acc_partial()
+        if part.is_cuda and not self._nccl:
+            host = part.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            part.copy_(host)
+        else:
+            dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
 
     def step_allpairs(self, nsteps=1):
         pair = self.world > 1 and getattr(self.backend, "pair_sharding", False)
@@ -115,7 +152,8 @@ class ShardedSim:
             if pair:
                 # every rank: its share of the pair tiles -> contributions to ALL bodies; sum them
                 self.backend.forces_partial(self.rank, self.world)
-                dist.all_reduce(self.backend.acc_partial(), op=dist.ReduceOp.SUM, group=self.group)
+                with self._stream():
+                    self._sum_partials()
                 self.backend.integrate_partial()
             else:
                 self.backend.step("allpairs")

@@ -28,15 +28,18 @@ assert be.pair_sharding
 be.upload(m, pos, vel)
 sim = ShardedSim(be, n, 0, 1)
 # world == 1 skips the collectives; drive them by hand exactly as ShardedSim does for world > 1
+assert be.torch_stream.cuda_stream != 0 and be.sim.stream() == be.torch_stream.cuda_stream
 for _ in range(2):
     be.forces_partial(0, 1)
-    part = be.acc_partial()
-    assert part.is_cuda and part.shape == (n, 4) and part.data_ptr() == be.sim.device_buffer(nb.BUF_ACC_PARTIAL)[0]
-    dist.all_reduce(part)
+    with torch.cuda.stream(be.torch_stream):
+        part = be.acc_partial()
+        assert part.is_cuda and part.shape == (n, 4) and part.data_ptr() == be.sim.device_buffer(nb.BUF_ACC_PARTIAL)[0]
+        dist.all_reduce(part)
     be.integrate_partial()
-    full = be.posm()
-    own = full[0:n].clone()
-    dist.all_gather_into_tensor(full, own)
+    with torch.cuda.stream(be.torch_stream):
+        full = be.posm()
+        own = full[0:n].clone()
+        dist.all_gather_into_tensor(full, own)
 torch.cuda.synchronize()
 p, v, a = be.download()
 assert np.array_equal(p, rp) and np.array_equal(v, rv) and np.array_equal(a, ra)

@@ -4,7 +4,8 @@
 One "step" = forces of all N sources on this rank's targets + velocity-Verlet integration +
 (N > 1 GPUs) the all-gather of the new positions.  Inputs are resident in HBM before timing.
 Prints ONE JSON line (rank 0).  Extra legs, outside the timed region: the reference's own WGSL
-law (acos/pow bias) on the same bodies, and the CPU baseline (the oracle's restatement of
+law (acos/pow bias) on the same bodies, Barnes-Hut steps at N = 1M and N = 16M (sharded the same
+way over the GPUs), and the CPU baseline (the oracle's restatement of
 src/nbody_cpu.rs timed on the host cores, rank 0 at --gpus 1 only).
 """
 import argparse
@@ -95,14 +96,23 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         kms, launches = be.sim.kernel_time()
+        agree = True
         if world > 1:
             t = torch.tensor([dt, kms], device="cuda", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt, kms = float(t[0]), float(t[1])
+            # every rank must hold the same gathered positions
+            with torch.cuda.stream(be.torch_stream):
+                cs = be.posm().to(torch.float64).sum().reshape(1)
+            torch.cuda.synchronize()
+            lo, hi = cs.clone(), cs.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            agree = bool(lo.item() == hi.item()) and bool(torch.isfinite(cs).item())
         be.sim.close()
-        return dt, kms, launches
+        return dt, kms, launches, agree
 
-    dt, kernel_ms, launches = timed_run(law, args.steps, args.warmup)
+    dt, kernel_ms, launches, agree = timed_run(law, args.steps, args.warmup)
     interactions = float(n) * n * args.steps
     flop = FLOP_PER_INTERACTION[args.law]
     # the dominant kernel: one launch covers this rank's share of the N x N interactions (its
@@ -149,44 +159,64 @@ def main():
     if not args.no_extras and args.law == "plummer":
         # the reference's shader law (src/nbody.wgsl:54-81) on the same bodies, fewer steps
         wsteps = max(1, min(2, args.steps))
-        wdt, wk, _ = timed_run(nb.LAW_WGSL_BIAS, wsteps, 1)
+        wdt, wk, _, wagree = timed_run(nb.LAW_WGSL_BIAS, wsteps, 1)
+        agree = agree and wagree
         wach = per_launch * FLOP_PER_INTERACTION["wgsl_bias"] / (wk * 1e-3) / 1e12 if wk > 0 else 0.0
         out["wgsl_bias_law"] = {"value": float(n) * n * wsteps / wdt, "unit": "interactions/s",
                                 "ms_per_step": wdt / wsteps * 1e3, "achieved_tflops": wach,
                                 "frac": wach / PEAK_FP32_TFLOPS, "steps": wsteps}
-    if not args.no_extras and world == 1:
-        # Barnes-Hut step (octree build + traversal + integrate/clamp), N = 1M, theta = 0.5, one GPU
-        with nb.NBodySim(n, law=nb.LAW_PLUMMER) as sim:
-            sim.upload(masses, pos, vel)
-            sim.step_bh(2)
-            sim.set_counting(True)
-            sim.accel_bh()
-            c = sim.counters()
-            sim.set_counting(False)
-            sim.set_kernel_timing(True)
-            sim.kernel_time(bh=True)
-            sim.sync()
-            t0 = time.perf_counter()
-            bsteps = 20
-            sim.step_bh(bsteps)
-            sim.sync()
-            bdt = time.perf_counter() - t0
-            wms, _ = sim.kernel_time(bh=True)
-        inter = c["bh_leaf_interactions"] + c["bh_aggregate_interactions"]
+
+    def bh_leg(nbodies, bsteps):
+        """Barnes-Hut step (replicated octree build + traversal of this rank's targets + integrate/clamp
+        + all-gather of the positions), theta = 0.5, depth cap 16, targets sharded over the ranks."""
+        m_, p_, v_ = (masses, pos, vel) if nbodies == n else nb.gen_plummer(nbodies, seed=42)
+        b_, c_ = shard_range(nbodies, rank, world)
+        be = HipShardBackend(nbodies, b_, c_, local_rank, law=nb.LAW_PLUMMER)
+        be.upload(m_, p_, v_)
+        sim = ShardedSim(be, nbodies, rank, world)
+        sim.step_bh(2)
+        be.sim.set_counting(True)
+        be.sim.accel_bh()          # counting build of the traversal kernel, own targets only
+        c = be.sim.counters()
+        be.sim.set_counting(False)
+        be.sim.set_kernel_timing(True)
+        be.sim.kernel_time(bh=True)
+        barrier()
+        t0 = time.perf_counter()
+        sim.step_bh(bsteps)
+        barrier()
+        bdt = time.perf_counter() - t0
+        wms, _ = be.sim.kernel_time(bh=True)
+        be.sim.close()
+        tot = torch.tensor([c["bh_leaf_interactions"] + c["bh_aggregate_interactions"], c["bh_node_visits"],
+                            c["bh_wave_node_visits"]], device="cuda", dtype=torch.float64)
+        mx = torch.tensor([bdt, wms], device="cuda", dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        inter, visits, wave_visits = (float(x) for x in tot)
+        bdt, wms = float(mx[0]), float(mx[1])
         # bytes the traversal asks for: 32 B per wavefront node visit + per-body reads/writes
-        walk_bytes = 32.0 * c["bh_wave_node_visits"] + n * (16 + 16 + 16)
-        out["barnes_hut"] = {"n_bodies": n, "theta": 0.5, "max_depth": 16, "steps_per_s": bsteps / bdt,
-                             "ms_per_step": bdt / bsteps * 1e3, "walk_kernel_ms": wms, "octree_nodes": c["octree_nodes"],
-                             "interactions_per_step": inter, "interactions_per_s": inter * bsteps / bdt,
-                             "node_visits_per_body": c["bh_node_visits"] / n,
-                             "wave_node_visits": c["bh_wave_node_visits"],
-                             "walk_requested_GBps": walk_bytes / (wms * 1e-3) / 1e9 if wms > 0 else None,
-                             "equivalent_allpairs_interactions_per_s": float(n) * n * bsteps / bdt}
+        walk_bytes = (32.0 * wave_visits + nbodies * (16 + 16 + 16)) / world
+        return {"n_bodies": nbodies, "n_gpus": world, "theta": 0.5, "max_depth": 16, "steps": bsteps,
+                "steps_per_s": bsteps / bdt, "ms_per_step": bdt / bsteps * 1e3, "walk_kernel_ms": wms,
+                "octree_nodes": c["octree_nodes"], "interactions_per_step": inter,
+                "interactions_per_s": inter * bsteps / bdt, "node_visits_per_body": visits / nbodies,
+                "wave_node_visits": wave_visits,
+                "walk_requested_GBps_per_gpu": walk_bytes / (wms * 1e-3) / 1e9 if wms > 0 else None,
+                "equivalent_allpairs_interactions_per_s": float(nbodies) * nbodies * bsteps / bdt}
+
+    if not args.no_extras and args.law == "plummer":
+        out["barnes_hut"] = bh_leg(n, 20)
+        if n == 1 << 20:
+            out["barnes_hut_16m"] = bh_leg(1 << 24, 5)
     if rank == 0 and args.gpus == 1 and not args.no_extras:
         try:
             out["cpu_baseline"] = cpu_baseline()
         except Exception as e:  # the oracle is a checker, never a dependency of the timed path
             out["cpu_baseline"] = {"error": str(e)}
+    if world > 1:
+        out["ranks_hold_identical_positions"] = agree
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -35,6 +35,12 @@ struct SymItem {
     uint32_t pad;
 };
 
+// Which part evaluates a work item: group g = item / nparts deals its nparts items out starting
+// at part g mod nparts, so that no part always gets the same position within a group.
+__device__ __forceinline__ uint32_t sym_owner(uint32_t item, uint32_t nparts) {
+    return (item % nparts + nparts - (item / nparts) % nparts) % nparts;
+}
+
 // UNIFORM: every body has the same mass, which is then applied once per body by the reduction
 // instead of twice per pair here.
 // P: targets per lane (superblock = 256 * P bodies), two per packed register pair.
@@ -48,8 +54,9 @@ __global__ __launch_bounds__(256) void k_ap_sym(const float4* __restrict__ posm,
     __shared__ float4 accj[3][4][2 * TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int SB = 256 * P, TILES_PER_SB = SB / TILE, H = P / 2;
-    // with nparts > 1 (one part per GPU) this launch takes every nparts-th work item
-    const uint32_t item_id = blockIdx.x * nparts + part;
+    // with nparts > 1 (one part per GPU) this launch takes one work item of every nparts
+    // consecutive ones, rotating which (see sym_owner)
+    const uint32_t item_id = blockIdx.x * nparts + (part + blockIdx.x) % nparts;
     if (item_id >= n_items) return;
     const SymItem it = items[item_id];
     const int ibase = (int)it.a * SB + wave * (64 * P) + lane;
@@ -181,7 +188,7 @@ __global__ void k_ap_sym_reduce(const float4* __restrict__ diag, const float4* _
     for (int a = 0; a < b; ++a) {
         // the work item that covered (a, j's tile); with nparts > 1 only this part's items count
         const uint32_t item = item_start[a] + (uint32_t)((j - (a + 1) * SB) / TILE) / seg;
-        if (item % nparts != part) continue;
+        if (sym_owner(item, nparts) != part) continue;
         const float4 p = part_j[rowoff[a] + (unsigned long long)(j - (a + 1) * SB)];
         x += p.x;
         y += p.y;
@@ -189,7 +196,7 @@ __global__ void k_ap_sym_reduce(const float4* __restrict__ diag, const float4* _
     }
     const uint32_t i0 = item_start[b], i1 = item_start[b + 1];
     for (uint32_t i = i0; i < i1; ++i) {
-        if (i % nparts != part) continue;
+        if (sym_owner(i, nparts) != part) continue;
         const float4 p = part_i[(size_t)i * SB + (j - b * SB)];
         x += p.x;
         y += p.y;

@@ -191,7 +191,8 @@ template <int IPT, bool BIAS = false>
 __global__ __launch_bounds__(BLOCK) void k_allpairs_plummer_pk(const float4* __restrict__ posm,
                                                                 float4* __restrict__ acc_part, int n, int i_begin,
                                                                 int i_count, int j_chunk, float eps2, int diag,
-                                                                const float4* __restrict__ vel = nullptr) {
+                                                                const float4* __restrict__ vel = nullptr,
+                                                                int slice_stride = 0) {
     static_assert(IPT % 2 == 0, "packed kernel needs an even number of targets per lane");
     constexpr int H = IPT / 2;
     __shared__ float4 tile[2][TJ];
@@ -218,10 +219,11 @@ __global__ __launch_bounds__(BLOCK) void k_allpairs_plummer_pk(const float4* __r
                        sqrtf(fmaf(v1.x, v1.x, fmaf(v1.y, v1.y, v1.z * v1.z)))};
         }
     }
-    // diag: the sources are the workgroup's own BLOCK*IPT targets only (the within-superblock
-    // term of the symmetric path)
-    const int j0 = diag ? ib : blockIdx.y * j_chunk;
-    const int j1 = min(n, j0 + (diag ? BLOCK * IPT : j_chunk));
+    // diag > 0: the sources are the `diag` bodies of the superblock that holds the workgroup's
+    // targets (the within-superblock term of the symmetric path), slice blockIdx.y of them; diag
+    // is a multiple of BLOCK*IPT and of j_chunk
+    const int j0 = (diag ? (ib / diag) * diag : 0) + blockIdx.y * j_chunk;
+    const int j1 = min(n, j0 + j_chunk);
     const int ntiles = (j1 - j0 + TJ - 1) / TJ;
 
     f2 sx[H], sy[H], sz[H], cx[H], cy[H], cz[H];
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(BLOCK) void k_allpairs_plummer_pk(const float4* __r
 #pragma unroll
     for (int k = 0; k < H; ++k) {
         int ig0 = ib + (2 * k) * BLOCK + tid, ig1 = ig0 + BLOCK;
-        float4* dst = acc_part + (size_t)blockIdx.y * i_count;
+        float4* dst = acc_part + (size_t)blockIdx.y * (slice_stride ? slice_stride : i_count);
         if (ig0 < i_end) dst[ig0 - i_begin] = make_float4(sx[k].x, sy[k].x, sz[k].x, 0.0f);
         if (ig1 < i_end) dst[ig1 - i_begin] = make_float4(sx[k].y, sy[k].y, sz[k].y, 0.0f);
     }
@@ -458,15 +460,18 @@ int nb_time_collect(nbody_ctx* ctx, int which) {
     return NBODY_OK;
 }
 
-// Un-scaled PLUMMER sums of every body over the sources of its own superblock (256 * tpl bodies).
+// Un-scaled PLUMMER sums of the context's own targets over the sources of their superblock
+// (256 * tpl bodies), one partial sum per NB_DIAG_TILE sources: diag_out[slice * n + body].  Two
+// targets per lane and sliced sources: enough workgroups to keep the chip busy with few superblocks.
 int nb_allpairs_diag(nbody_ctx* ctx, const float4* posm_in, float4* diag_out, int tpl) {
-    dim3 grid((unsigned)((ctx->n + BLOCK * tpl - 1) / (BLOCK * tpl)), 1);
-    if (tpl == 8)
-        hipLaunchKernelGGL((k_allpairs_plummer_pk<8>), grid, dim3(BLOCK), 0, ctx->stream, posm_in, diag_out, (int)ctx->n, 0,
-                           (int)ctx->n, 0, ctx->cfg.eps2, 1);
-    else
-        hipLaunchKernelGGL((k_allpairs_plummer_pk<4>), grid, dim3(BLOCK), 0, ctx->stream, posm_in, diag_out, (int)ctx->n, 0,
-                           (int)ctx->n, 0, ctx->cfg.eps2, 1);
+    constexpr int IPT = 2, WG = BLOCK * IPT;
+    const int sb = BLOCK * tpl;
+    static_assert(NB_DIAG_TILE == TJ, "one slice per LDS tile");
+    const int first = (int)(ctx->i_begin / WG) * WG;  // whole workgroups; the few extra bodies are ignored by the caller
+    const int last = (int)std::min<uint64_t>(ctx->n, (ctx->i_begin + ctx->i_count + WG - 1) / WG * WG);
+    dim3 grid((unsigned)((last - first + WG - 1) / WG), (unsigned)(sb / TJ));
+    hipLaunchKernelGGL((k_allpairs_plummer_pk<IPT>), grid, dim3(BLOCK), 0, ctx->stream, posm_in, diag_out + first, (int)ctx->n,
+                       first, last - first, TJ, ctx->cfg.eps2, sb, (const float4*)nullptr, (int)ctx->n);
     NB_HIP(ctx, hipGetLastError());
     return NBODY_OK;
 }

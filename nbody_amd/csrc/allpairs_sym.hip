@@ -176,43 +176,74 @@ __global__ __launch_bounds__(256) void k_ap_sym(const float4* __restrict__ posm,
 
 // acc_out[j] = G * ( diag[j] + sum over earlier superblocks a of part_j[a][j]
 //                             + sum over the items of j's superblock of part_i[item][j] ), in f64.
+template <bool SINGLE>  // SINGLE: nparts == 1, every row counts and the loads are issued in batches
 __global__ void k_ap_sym_reduce(const float4* __restrict__ diag, const float4* __restrict__ part_j,
                                 const float4* __restrict__ part_i, const unsigned long long* __restrict__ rowoff,
                                 const uint32_t* __restrict__ item_start, int n, int SB, uint32_t seg, float G,
                                 float pair_scale, uint32_t part, uint32_t nparts, int own_begin, int own_end,
-                                float4* __restrict__ acc_out) {
+                                int diag_slices, float4* __restrict__ acc_out) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const int b = j / SB;
     double x = 0.0, y = 0.0, z = 0.0;
-    for (int a = 0; a < b; ++a) {
+    constexpr int U = SINGLE ? 4 : 1;
+    int a = 0;
+    if (SINGLE) {
+        for (; a + U <= b; a += U) {
+            float4 p[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) p[u] = part_j[rowoff[a + u] + (unsigned long long)(j - (a + u + 1) * SB)];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                x += p[u].x;
+                y += p[u].y;
+                z += p[u].z;
+            }
+        }
+    }
+    for (; a < b; ++a) {
         // the work item that covered (a, j's tile); with nparts > 1 only this part's items count
         const uint32_t item = item_start[a] + (uint32_t)((j - (a + 1) * SB) / TILE) / seg;
-        if (sym_owner(item, nparts) != part) continue;
+        if (!SINGLE && sym_owner(item, nparts) != part) continue;
         const float4 p = part_j[rowoff[a] + (unsigned long long)(j - (a + 1) * SB)];
         x += p.x;
         y += p.y;
         z += p.z;
     }
     const uint32_t i0 = item_start[b], i1 = item_start[b + 1];
-    for (uint32_t i = i0; i < i1; ++i) {
-        if (sym_owner(i, nparts) != part) continue;
+    uint32_t i = i0;
+    if (SINGLE) {
+        for (; i + U <= i1; i += U) {
+            float4 p[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) p[u] = part_i[(size_t)(i + u) * SB + (j - b * SB)];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                x += p[u].x;
+                y += p[u].y;
+                z += p[u].z;
+            }
+        }
+    }
+    for (; i < i1; ++i) {
+        if (!SINGLE && sym_owner(i, nparts) != part) continue;
         const float4 p = part_i[(size_t)i * SB + (j - b * SB)];
         x += p.x;
         y += p.y;
         z += p.z;
     }
     // pair_scale: the common mass when the pair kernel left the masses out; the within-superblock
-    // term always carries its masses
     // term always carries its masses; it is added by the part that owns the body
     x *= (double)pair_scale;
     y *= (double)pair_scale;
     z *= (double)pair_scale;
     if (j >= own_begin && j < own_end) {
-        const float4 d = diag[j];
-        x += d.x;
-        y += d.y;
-        z += d.z;
+        for (int s = 0; s < diag_slices; ++s) {
+            const float4 d = diag[(size_t)s * n + j];
+            x += d.x;
+            y += d.y;
+            z += d.z;
+        }
     }
     acc_out[j] = make_float4(G * (float)x, G * (float)y, G * (float)z, 0.0f);
 }
@@ -252,7 +283,7 @@ uint64_t nb_sym_scratch_bytes(uint64_t n, uint32_t seg_tiles, uint32_t SB) {
         rows += tiles * TILE;
         items += (tiles + seg_tiles - 1) / seg_tiles;
     }
-    return (rows + items * SB + n) * sizeof(float4);
+    return (rows + items * SB + (SB / NB_DIAG_TILE) * n) * sizeof(float4);
 }
 
 static int sym_prepare(nbody_ctx* ctx, uint32_t seg_tiles, uint32_t SB) {
@@ -287,7 +318,7 @@ static int sym_prepare(nbody_ctx* ctx, uint32_t seg_tiles, uint32_t SB) {
     NB_HIP(ctx, hipMalloc(&P->item_start, item_start.size() * sizeof(uint32_t)));
     NB_HIP(ctx, hipMalloc(&P->part_j, std::max<unsigned long long>(1, rows) * sizeof(float4)));
     NB_HIP(ctx, hipMalloc(&P->part_i, std::max<size_t>(1, items.size()) * SB * sizeof(float4)));
-    NB_HIP(ctx, hipMalloc(&P->diag, n * sizeof(float4)));
+    NB_HIP(ctx, hipMalloc(&P->diag, (size_t)(SB / NB_DIAG_TILE) * n * sizeof(float4)));
     NB_HIP(ctx, hipMemcpyAsync(P->items, items.data(), items.size() * sizeof(SymItem), hipMemcpyHostToDevice, ctx->stream));
     NB_HIP(ctx, hipMemcpyAsync(P->rowoff, rowoff.data(), rowoff.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, ctx->stream));
     NB_HIP(ctx, hipMemcpyAsync(P->item_start, item_start.data(), item_start.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
@@ -322,9 +353,14 @@ int nb_allpairs_forces_sym(nbody_ctx* ctx, const float4* posm_in, float4* acc_ou
     NB_HIP(ctx, hipGetLastError());
     r = nb_allpairs_diag(ctx, posm_in, P->diag, tpl);
     if (r) return r;
-    hipLaunchKernelGGL(k_ap_sym_reduce, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, P->diag, P->part_j, P->part_i,
-                       P->rowoff, P->item_start, n, (int)SB, P->seg, ctx->cfg.G, uniform ? ctx->mass0 : 1.0f, part, nparts,
-                       (int)ctx->i_begin, (int)(ctx->i_begin + ctx->i_count), acc_out);
+    if (nparts == 1)
+        hipLaunchKernelGGL(k_ap_sym_reduce<true>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, P->diag, P->part_j, P->part_i,
+                           P->rowoff, P->item_start, n, (int)SB, P->seg, ctx->cfg.G, uniform ? ctx->mass0 : 1.0f, part, nparts,
+                           (int)ctx->i_begin, (int)(ctx->i_begin + ctx->i_count), (int)(SB / NB_DIAG_TILE), acc_out);
+    else
+        hipLaunchKernelGGL(k_ap_sym_reduce<false>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, P->diag, P->part_j, P->part_i,
+                           P->rowoff, P->item_start, n, (int)SB, P->seg, ctx->cfg.G, uniform ? ctx->mass0 : 1.0f, part, nparts,
+                           (int)ctx->i_begin, (int)(ctx->i_begin + ctx->i_count), (int)(SB / NB_DIAG_TILE), acc_out);
     NB_HIP(ctx, hipGetLastError());
     ctx->counters.interactions_allpairs += ctx->n * ctx->n / nparts;
     return NBODY_OK;

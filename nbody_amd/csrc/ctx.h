@@ -86,6 +86,8 @@ int nb_allpairs_forces_sym(nbody_ctx* ctx, const float4* posm_in, float4* acc_ou
 int nb_allpairs_partial(nbody_ctx* ctx, uint32_t part, uint32_t nparts);
 uint64_t nb_sym_scratch_bytes(uint64_t n, uint32_t seg_tiles, uint32_t sb);
 void nb_sym_destroy(nbody_ctx* ctx);
+// diag_out: 256 * tpl / NB_DIAG_TILE slices of n entries each, to be summed
+constexpr int NB_DIAG_TILE = 512;
 int nb_allpairs_diag(nbody_ctx* ctx, const float4* posm_in, float4* diag_out, int tpl);
 
 // octree (octree.hip)

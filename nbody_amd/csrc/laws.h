@@ -37,10 +37,37 @@ __device__ __forceinline__ float rsq_refined(float x) {
     return fmaf(y, e, y);
 }
 
+// The factor sc of one source term sc * d for the WGSL laws, from the separation
+// d = source - target and its squared length r2u (no softening in it).
+template <int LAW, bool PRECISE>
+__device__ __forceinline__ float pair_scale(const Tgt& t, float dx, float dy, float dz, float r2u, float mass, float eps2) {
+    static_assert(LAW != NBODY_LAW_CPU_R6, "WGSL laws only");
+    const float rinv = PRECISE ? rsq_refined(r2u + eps2) : __builtin_amdgcn_rsqf(r2u + eps2);
+    float sc = (mass * rinv) * (rinv * rinv);  // src/nbody.wgsl:56-65
+    if (LAW == NBODY_LAW_WGSL_BIAS) {          // src/nbody.wgsl:74-79
+        const float dist = __builtin_amdgcn_sqrtf(r2u);
+        const float vd = fmaf(t.vx, dx, fmaf(t.vy, dy, t.vz * dz));
+        const float q = vd * __builtin_amdgcn_rcpf(fmaf(dist, t.vn, 1.0f));
+        sc *= __builtin_amdgcn_exp2f(0.15f * __builtin_amdgcn_logf(fast_acos(q)));
+    }
+    return sc;
+}
+
+template <int LAW, bool SELF, bool PRECISE = false>
+__device__ __forceinline__ void interact_d(const Tgt& t, float dx, float dy, float dz, float mass, int jglob, float eps2,
+                                           float& ax, float& ay, float& az);
+
 template <int LAW, bool SELF, bool PRECISE = false>
 __device__ __forceinline__ void interact(const Tgt& t, const float4 s, int jglob, float eps2, float& ax, float& ay,
                                          float& az) {
-    float dx = s.x - t.x, dy = s.y - t.y, dz = s.z - t.z;
+    interact_d<LAW, SELF, PRECISE>(t, s.x - t.x, s.y - t.y, s.z - t.z, s.w, jglob, eps2, ax, ay, az);
+}
+
+// The same with the separation d = source - target already formed.
+template <int LAW, bool SELF, bool PRECISE>
+__device__ __forceinline__ void interact_d(const Tgt& t, float dx, float dy, float dz, float mass, int jglob, float eps2,
+                                           float& ax, float& ay, float& az) {
+    const struct { float w; } s = {mass};
     float sc;
     if (LAW == NBODY_LAW_CPU_R6) {
         // src/nbody_cpu.rs:337-340: m*d / (d.d)^3

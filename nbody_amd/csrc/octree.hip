@@ -36,16 +36,32 @@ constexpr int NCNT = 18;       // level counters 0..16 + leaf-list members
 constexpr int LIST_ROW = 17;
 constexpr uint32_t NO_NODE = 0xffffffffu;
 
-// Node record (32 B): written by the build, fetched by the traversal with one s_load_dwordx8.
+// Node record (32 B): written by the build, fetched by the traversal with scalar loads.
 // Breadth-first numbering makes the children of a node (octant order) and the members of a leaf
 // list consecutive: [first, first + count).
+// The acceptance test range / distance < theta (src/nbodybh.wgsl:104-106) is prepared per node
+// as two thresholds on the squared distance: r^2 > r2_accept settles "accept", r^2 < r2_open
+// settles "open"; in the narrow band between them (relative width 8e-6) the traversal evaluates
+// the reference's expression itself, with the node's range from a side array.
 struct QNode {
     float cx, cy, cz, mass;
-    float range;
-    uint32_t type;
+    float r2_open, r2_accept;
     uint32_t first;
-    uint32_t count;
+    uint32_t count_type;  // count in the low 30 bits, nbody_node_type in the top two
 };
+__host__ __device__ __forceinline__ uint32_t qn_type(const QNode& nd) { return nd.count_type >> 30; }
+__host__ __device__ __forceinline__ uint32_t qn_count(const QNode& nd) { return nd.count_type & 0x3fffffffu; }
+__host__ __device__ __forceinline__ uint32_t qn_pack(uint32_t count, uint32_t type) { return (type << 30) | count; }
+
+// 1 / (theta^2 (1 +- 4e-6)): the squared-distance thresholds of a node are range^2 times these.
+struct MacScale {
+    float open, accept;
+};
+__device__ __forceinline__ void qn_set_range(QNode& nd, float range, MacScale mac) {
+    const float q = range * range;
+    nd.r2_open = q * mac.open;
+    nd.r2_accept = q * mac.accept;
+}
 static_assert(sizeof(QNode) == 32, "node record layout");
 
 }  // namespace
@@ -74,6 +90,7 @@ struct Octree {
     QNode* nodes = nullptr;
     float4* bmin = nullptr;          // bounding box of the bodies below each node
     float4* bmax = nullptr;
+    float* range = nullptr;          // longest side of that box (src/octree_maxdepth.rs:101)
     uint32_t* node_head = nullptr;   // sorted rank of the first body of each node's cell
     uint64_t cap_nodes = 0;
     uint64_t n_nodes = 0;
@@ -299,7 +316,7 @@ __global__ __launch_bounds__(256) void k_emit(const uint64_t* __restrict__ keys,
                                               const uint8_t* __restrict__ lo, const uint8_t* __restrict__ top,
                                               const uint8_t* __restrict__ flags, const uint32_t* __restrict__ blk,
                                               uint32_t nb, const uint32_t* __restrict__ lvl_start, QNode* __restrict__ nodes,
-                                              float4* __restrict__ bmin, float4* __restrict__ bmax,
+                                              float4* __restrict__ bmin, float4* __restrict__ bmax, float* __restrict__ range,
                                               uint32_t* __restrict__ node_head, uint32_t* __restrict__ body_node,
                                               uint32_t cap_nodes, uint32_t* __restrict__ err_flag) {
     __shared__ uint32_t wtot[NCNT][4];
@@ -354,11 +371,11 @@ __global__ __launch_bounds__(256) void k_emit(const uint64_t* __restrict__ keys,
                 else type = NBODY_NODE_LEAFBODY;
                 QNode nd;
                 nd.cx = p.x; nd.cy = p.y; nd.cz = p.z; nd.mass = p.w;  // src/octree_maxdepth.rs:75-86 for a LEAFBODY;
-                nd.range = 0.0f;                                       // aggregates are filled in later otherwise
-                nd.type = type;
+                nd.r2_open = nd.r2_accept = 0.0f;                      // aggregates are filled in later otherwise
                 nd.first = 0;
-                nd.count = 0;
+                nd.count_type = qn_pack(0, type);
                 nodes[id] = nd;
+                range[id] = 0.0f;
                 bmin[id] = make_float4(p.x, p.y, p.z, 0.0f);
                 bmax[id] = make_float4(p.x, p.y, p.z, 0.0f);
                 node_head[id] = i;
@@ -376,7 +393,8 @@ __global__ __launch_bounds__(256) void k_emit(const uint64_t* __restrict__ keys,
 __global__ void k_leaflist(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idx,
                            const float4* __restrict__ posm, uint32_t n, int list_mode, const uint8_t* __restrict__ flags,
                            const uint32_t* __restrict__ body_node, QNode* __restrict__ nodes, float4* __restrict__ bmin,
-                           float4* __restrict__ bmax, uint32_t* __restrict__ node_head, uint32_t cap_nodes) {
+                           float4* __restrict__ bmax, float* __restrict__ range, uint32_t* __restrict__ node_head,
+                           uint32_t cap_nodes, MacScale mac) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || !(flags[i] & 2u)) return;
     const uint32_t id = body_node[i];
@@ -391,11 +409,11 @@ __global__ void k_leaflist(const uint64_t* __restrict__ keys, const uint32_t* __
         if (member < cap_nodes) {
             QNode c;
             c.cx = q.x; c.cy = q.y; c.cz = q.z; c.mass = q.w;
-            c.range = 0.0f;
-            c.type = NBODY_NODE_LEAFBODY;
+            c.r2_open = c.r2_accept = 0.0f;
             c.first = 0;
-            c.count = 0;
+            c.count_type = qn_pack(0, NBODY_NODE_LEAFBODY);
             nodes[member] = c;
+            range[member] = 0.0f;
             bmin[member] = make_float4(q.x, q.y, q.z, 0.0f);
             bmax[member] = make_float4(q.x, q.y, q.z, 0.0f);
             node_head[member] = i;
@@ -417,9 +435,11 @@ __global__ void k_leaflist(const uint64_t* __restrict__ keys, const uint32_t* __
         mxx = fmaxf(mxx, b.x); mxy = fmaxf(mxy, b.y); mxz = fmaxf(mxz, b.z);
     }
     nd.cx = a.x; nd.cy = a.y; nd.cz = a.z; nd.mass = a.w;
-    nd.range = fmaxf(mxx - mnx, fmaxf(mxy - mny, mxz - mnz));
-    nd.count = count;
+    const float rg = fmaxf(mxx - mnx, fmaxf(mxy - mny, mxz - mnz));
+    qn_set_range(nd, rg, mac);
+    nd.count_type = qn_pack(count, NBODY_NODE_LEAFLIST);
     nodes[id] = nd;
+    range[id] = rg;
     bmin[id] = make_float4(mnx, mny, mnz, 0.0f);
     bmax[id] = make_float4(mxx, mxy, mxz, 0.0f);
 }
@@ -428,12 +448,12 @@ __global__ void k_leaflist(const uint64_t* __restrict__ keys, const uint32_t* __
 // One level: nodes [first_id, first_id + count).  The children of a node end where the next
 // node's begin (`child_end` for the last node of the level).
 __global__ void k_aggregate(QNode* __restrict__ nodes, float4* __restrict__ bmin, float4* __restrict__ bmax,
-                            uint32_t first_id, uint32_t count, uint32_t child_end) {
+                            float* __restrict__ range, uint32_t first_id, uint32_t count, uint32_t child_end, MacScale mac) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= count) return;
     const uint32_t id = first_id + r;
     QNode nd = nodes[id];
-    if (nd.type != NBODY_NODE_INTERIOR) return;
+    if (qn_type(nd) != NBODY_NODE_INTERIOR) return;
     const uint32_t c0 = nd.first, c1 = (r + 1 < count) ? nodes[id + 1].first : child_end;
     float M = 0.0f, wx = 0.0f, wy = 0.0f, wz = 0.0f;
     float mnx = INFINITY, mny = INFINITY, mnz = INFINITY, mxx = -INFINITY, mxy = -INFINITY, mxz = -INFINITY;
@@ -451,16 +471,18 @@ __global__ void k_aggregate(QNode* __restrict__ nodes, float4* __restrict__ bmin
     nd.cx = wx / M;
     nd.cy = wy / M;
     nd.cz = wz / M;
-    nd.range = fmaxf(mxx - mnx, fmaxf(mxy - mny, mxz - mnz));  // src/octree_maxdepth.rs:101
-    nd.count = c1 - c0;
+    const float rg = fmaxf(mxx - mnx, fmaxf(mxy - mny, mxz - mnz));  // src/octree_maxdepth.rs:101
+    qn_set_range(nd, rg, mac);
+    nd.count_type = qn_pack(c1 - c0, NBODY_NODE_INTERIOR);
     nodes[id] = nd;
+    range[id] = rg;
     bmin[id] = make_float4(mnx, mny, mnz, 0.0f);
     bmax[id] = make_float4(mxx, mxy, mxz, 0.0f);
 }
 
 // ---- export / import (96-byte reference layout) ---------------------------------------------
 __global__ void k_export(const QNode* __restrict__ nodes, const float4* __restrict__ bmin, const float4* __restrict__ bmax,
-                         const uint32_t* __restrict__ node_head, const uint64_t* __restrict__ keys,
+                         const float* __restrict__ range, const uint32_t* __restrict__ node_head, const uint64_t* __restrict__ keys,
                          const uint32_t* __restrict__ lvl_start, int D, uint32_t count, nbody_octree_node* __restrict__ out) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= count) return;
@@ -472,18 +494,19 @@ __global__ void k_export(const QNode* __restrict__ nodes, const float4* __restri
     o.center_of_mass[0] = nd.cx; o.center_of_mass[1] = nd.cy; o.center_of_mass[2] = nd.cz; o._pad0 = 0.0f;
     o.pos_min[0] = lo.x; o.pos_min[1] = lo.y; o.pos_min[2] = lo.z; o._pad1 = 0.0f;
     o.pos_max[0] = hi.x; o.pos_max[1] = hi.y; o.pos_max[2] = hi.z;
-    o.range = nd.range;
+    o.range = range[id];
     o.total_mass = nd.mass;
     for (int k = 0; k < 8; ++k) o.child_indices[k] = 0;
-    if (nd.type == NBODY_NODE_INTERIOR) {
+    const uint32_t type = qn_type(nd), cnt = qn_count(nd);
+    if (type == NBODY_NODE_INTERIOR) {
         // the octant of a child is the digit of its bodies' keys at the child's level
-        for (uint32_t c = nd.first; c < nd.first + nd.count; ++c)
+        for (uint32_t c = nd.first; c < nd.first + cnt; ++c)
             o.child_indices[(uint32_t)(keys[node_head[c]] >> (3 * (D - depth - 1))) & 7u] = c;
-    } else if (nd.type == NBODY_NODE_LEAFLIST) {
+    } else if (type == NBODY_NODE_LEAFLIST) {
         o.child_indices[0] = nd.first;
-        o.child_indices[1] = nd.count;
+        o.child_indices[1] = cnt;
     }
-    o.node_type = nd.type;
+    o.node_type = type;
     o.depth = (uint32_t)depth;
     o._pad2 = 0;
     out[id] = o;
@@ -491,32 +514,34 @@ __global__ void k_export(const QNode* __restrict__ nodes, const float4* __restri
 
 // Uploaded trees arrive renumbered breadth-first by the host: children consecutive in octant order.
 __global__ void k_import(const nbody_octree_node* __restrict__ in, uint32_t count, QNode* __restrict__ nodes,
-                         float4* __restrict__ bmin, float4* __restrict__ bmax, uint32_t* __restrict__ err_flag) {
+                         float4* __restrict__ bmin, float4* __restrict__ bmax, float* __restrict__ range, MacScale mac,
+                         uint32_t* __restrict__ err_flag) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= count) return;
     const nbody_octree_node o = in[id];
     QNode nd;
     nd.cx = o.center_of_mass[0]; nd.cy = o.center_of_mass[1]; nd.cz = o.center_of_mass[2];
     nd.mass = o.total_mass;
-    nd.range = o.range;
-    nd.type = o.node_type;
+    qn_set_range(nd, o.range, mac);
     nd.first = 0;
-    nd.count = 0;
+    uint32_t cnt = 0;
     if (o.node_type == NBODY_NODE_INTERIOR) {
         uint32_t last = 0;
         for (int k = 0; k < 8; ++k) {
             const uint32_t c = o.child_indices[k];
             if (c == 0) continue;
-            if (nd.count == 0) nd.first = c;
+            if (cnt == 0) nd.first = c;
             else if (c != last + 1) *err_flag = 3;
             last = c;
-            ++nd.count;
+            ++cnt;
         }
     } else if (o.node_type == NBODY_NODE_LEAFLIST) {
         nd.first = o.child_indices[0];
-        nd.count = max(o.child_indices[1], 1u);  // src/nbodybh.wgsl:139-146 is a do-while: at least one member
+        cnt = max(o.child_indices[1], 1u);  // src/nbodybh.wgsl:139-146 is a do-while: at least one member
     }
+    nd.count_type = qn_pack(cnt, o.node_type);
     nodes[id] = nd;
+    range[id] = o.range;
     bmin[id] = make_float4(o.pos_min[0], o.pos_min[1], o.pos_min[2], 0.0f);
     bmax[id] = make_float4(o.pos_max[0], o.pos_max[1], o.pos_max[2], 0.0f);
 }
@@ -574,13 +599,16 @@ __global__ __launch_bounds__(256) void k_compact_scatter(const uint32_t* __restr
 // The children of a node are CONTIGUOUS (breadth-first numbering; uploaded trees are renumbered on
 // the host), so a node that must be opened is pushed as (first child, count, lane mask) and its
 // children are fetched together when it is popped.
+constexpr bool WALK_PRECISE = false;  // one Newton step on v_rsq_f32 in the traversal's interactions
 constexpr int WALK_STACK = 160;  // >= 8 pushes per level x 17 levels + root
+constexpr int WALK_BATCH = 4;    // node records fetched together; the node array is padded by as many
 
 template <int LAW, bool COUNT>
 __global__ __launch_bounds__(256) void k_walk(const QNode* __restrict__ q, const uint32_t* __restrict__ order, uint32_t m,
                                               uint32_t i_begin, const float4* __restrict__ posm,
                                               const float4* __restrict__ vel, float4* __restrict__ acc_out, float G,
-                                              float eps2, float theta, unsigned long long* __restrict__ counters,
+                                              float eps2, float theta, const float* __restrict__ range,
+                                              unsigned long long* __restrict__ counters,
                                               uint32_t* __restrict__ err_flag) {
     __shared__ uint4 st[4][WALK_STACK];  // {first, count, mask.lo, mask.hi}
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -601,11 +629,6 @@ __global__ __launch_bounds__(256) void k_walk(const QNode* __restrict__ q, const
     }
     float ax = 0.0f, ay = 0.0f, az = 0.0f;
     uint32_t n_visit = 0, n_leaf = 0, n_agg = 0, n_wave = 0, max_top = 0;
-    // The acceptance test is src/nbodybh.wgsl:104-106, range / distance < theta, with IEEE
-    // division and square root.  A cheap estimate (range * rsq(r^2), relative error < 1e-6)
-    // settles every case outside a 2e-6 band around theta; inside it the exact expression decides.
-    const float th_lo = theta * (1.0f - 2e-6f), th_hi = theta * (1.0f + 2e-6f);
-
     uint4* stack = st[wave];
     int top = 0;
     const unsigned long long all = __ballot(valid);
@@ -623,51 +646,59 @@ __global__ __launch_bounds__(256) void k_walk(const QNode* __restrict__ q, const
         const uint32_t mhi = (uint32_t)__builtin_amdgcn_readfirstlane(e.w);
         const unsigned long long mask = ((unsigned long long)mhi << 32) | (unsigned long long)mlo;
         const bool active = (mask >> lane) & 1ull;
-        for (uint32_t b0 = 0; b0 < cnt; b0 += 8) {
-            const uint32_t nb = min(8u, cnt - b0);
-            QNode c[8];
+        for (uint32_t b0 = 0; b0 < cnt; b0 += WALK_BATCH) {
+            const uint32_t nb = min((uint32_t)WALK_BATCH, cnt - b0);
+            // All records of the batch are fetched before the first use, from consecutive
+            // addresses whether the group has that many or not (the array is padded).
+            QNode c[WALK_BATCH];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) c[k] = q[first + b0 + min((uint32_t)k, nb - 1)];  // all fetched before the first use
-            if (top + 8 > WALK_STACK) {
+            for (int k = 0; k < WALK_BATCH; ++k) c[k] = q[first + b0 + k];
+            if (top + WALK_BATCH > WALK_STACK) {
                 if (lane == 0) *err_flag = 2;
                 top = 0;
                 break;
             }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < WALK_BATCH; ++k) {
                 if ((uint32_t)k >= nb) break;
                 const QNode nd = c[k];
                 if (COUNT) {
                     n_wave += (lane == 0);
                     n_visit += active;
                 }
-                const float4 src = make_float4(nd.cx, nd.cy, nd.cz, nd.mass);
-                if (nd.type == NBODY_NODE_LEAFBODY) {  // src/nbodybh.wgsl:76-102
-                    if (active) {
-                        interact<LAW, false, true>(t, src, 0, eps2, ax, ay, az);
-                        if (COUNT) ++n_leaf;
+                const float dx = nd.cx - t.x, dy = nd.cy - t.y, dz = nd.cz - t.z;
+                const float r2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+                bool take = active;  // LEAFBODY: a direct interaction (src/nbodybh.wgsl:76-102)
+                if (qn_type(nd) != NBODY_NODE_LEAFBODY) {
+                    // src/nbodybh.wgsl:104-106 by the node's squared-distance thresholds; the
+                    // reference's own expression decides inside the band between them
+                    bool accept = r2 > nd.r2_accept;
+                    const bool unsure = !accept && !(r2 < nd.r2_open);
+                    if (__ballot(active && unsure) != 0ull) {
+                        const float rg = range[first + b0 + k];
+                        const float rr = sqrtf(((dx * dx) + (dy * dy)) + (dz * dz));  // distance(pos, com)
+                        const bool exact = (rg / rr) < theta;
+                        accept = unsure ? exact : accept;
                     }
-                    continue;
+                    take = active && accept;
+                    const unsigned long long open = __ballot(active && !accept);
+                    if (open) {
+                        // INTERIOR: its children; LEAFLIST: its members (LEAFBODY records, src/nbodybh.wgsl:137-146)
+                        stack[top] = make_uint4(nd.first, qn_count(nd), (uint32_t)open, (uint32_t)(open >> 32));
+                        ++top;
+                        if (COUNT) max_top = max(max_top, (uint32_t)top);
+                    }
+                    if (COUNT) n_agg += take;
+                } else if (COUNT) {
+                    n_leaf += take;
                 }
-                const float dx = t.x - nd.cx, dy = t.y - nd.cy, dz = t.z - nd.cz;
-                const float est = nd.range * __builtin_amdgcn_rsqf(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
-                bool accept = est < th_lo;
-                const bool unsure = !accept && !(est > th_hi);
-                if (__any(active && unsure)) {
-                    const float rr = sqrtf(((dx * dx) + (dy * dy)) + (dz * dz));  // distance(pos, com)
-                    const bool exact = (nd.range / rr) < theta;
-                    accept = unsure ? exact : accept;
-                }
-                if (active && accept) {
-                    interact<LAW, false, true>(t, src, 0, eps2, ax, ay, az);
-                    if (COUNT) ++n_agg;
-                }
-                const unsigned long long open = __ballot(active && !accept);
-                if (open) {
-                    // INTERIOR: its children; LEAFLIST: its members (LEAFBODY records, src/nbodybh.wgsl:137-146)
-                    stack[top] = make_uint4(nd.first, nd.count, (uint32_t)open, (uint32_t)(open >> 32));
-                    ++top;
-                    if (COUNT) max_top = max(max_top, (uint32_t)top);
+                if (__ballot(take) != 0ull) {
+                    // every lane evaluates the term; lanes that do not take it add zero
+                    const float sc = pair_scale<LAW, WALK_PRECISE>(t, dx, dy, dz, r2, nd.mass, eps2);
+                    const float w = take ? sc : 0.0f;
+                    ax = fmaf(w, dx, ax);
+                    ay = fmaf(w, dy, ay);
+                    az = fmaf(w, dz, az);
                 }
             }
         }
@@ -682,6 +713,13 @@ __global__ __launch_bounds__(256) void k_walk(const QNode* __restrict__ q, const
     }
 }
 
+// theta == 0 gives infinite (or, for a zero range, NaN) thresholds: nothing is accepted by
+// them and the reference's expression, evaluated in the band, opens every node as it should.
+MacScale mac_scale(const nbody_ctx* ctx) {
+    const float th2 = ctx->cfg.theta * ctx->cfg.theta;
+    return MacScale{1.0f / (th2 * (1.0f + 4e-6f)), 1.0f / (th2 * (1.0f - 4e-6f))};
+}
+
 int ensure_nodes(nbody_ctx* ctx, Octree* T, uint64_t need) {
     if (need <= T->cap_nodes) return NBODY_OK;
     uint64_t cap = std::max<uint64_t>(need + need / 4 + 1024, 2 * T->n + 1024);
@@ -691,10 +729,14 @@ int ensure_nodes(nbody_ctx* ctx, Octree* T, uint64_t need) {
     T->node_head = nullptr;
     if (T->bmin) NB_HIP(ctx, hipFree(T->bmin));
     if (T->bmax) NB_HIP(ctx, hipFree(T->bmax));
+    if (T->range) NB_HIP(ctx, hipFree(T->range));
+    T->range = nullptr;
     T->nodes = nullptr;
     T->bmin = T->bmax = nullptr;
     T->cap_nodes = 0;
-    NB_HIP(ctx, hipMalloc(&T->nodes, cap * sizeof(QNode)));
+    // the traversal fetches whole batches: pad so that the last group's batch stays inside
+    NB_HIP(ctx, hipMalloc(&T->nodes, (cap + WALK_BATCH) * sizeof(QNode)));
+    NB_HIP(ctx, hipMalloc(&T->range, cap * sizeof(float)));
     NB_HIP(ctx, hipMalloc(&T->node_head, cap * sizeof(uint32_t)));
     NB_HIP(ctx, hipMalloc(&T->bmin, cap * sizeof(float4)));
     NB_HIP(ctx, hipMalloc(&T->bmax, cap * sizeof(float4)));
@@ -722,11 +764,11 @@ void launch_walk(nbody_ctx* ctx, Octree* T, const uint32_t* order, uint32_t m, c
     dim3 grid((m + 255) / 256);
     if (ctx->counting)
         hipLaunchKernelGGL((k_walk<LAW, true>), grid, dim3(256), 0, ctx->stream, T->nodes, order, m, (uint32_t)ctx->i_begin,
-                           posm, vel, acc_out, ctx->cfg.G, ctx->cfg.eps2, ctx->cfg.theta,
+                           posm, vel, acc_out, ctx->cfg.G, ctx->cfg.eps2, ctx->cfg.theta, T->range,
                            (unsigned long long*)T->walk_counters, T->err_flag);
     else
         hipLaunchKernelGGL((k_walk<LAW, false>), grid, dim3(256), 0, ctx->stream, T->nodes, order, m, (uint32_t)ctx->i_begin,
-                           posm, vel, acc_out, ctx->cfg.G, ctx->cfg.eps2, ctx->cfg.theta,
+                           posm, vel, acc_out, ctx->cfg.G, ctx->cfg.eps2, ctx->cfg.theta, T->range,
                            (unsigned long long*)T->walk_counters, T->err_flag);
 }
 
@@ -772,7 +814,7 @@ void nb_tree_destroy(nbody_ctx* ctx) {
         if (T->idx[s]) hipFree(T->idx[s]);
     }
     void* ptrs[] = {T->lo, T->top, T->flags, T->body_node, T->rs_counts, T->row_total, T->row_base, T->blk,
-                    T->lvl_total, T->lvl_start, T->nodes, T->node_head, T->bmin, T->bmax, T->export_buf, T->shard_order, T->shard_blk,
+                    T->lvl_total, T->lvl_start, T->nodes, T->node_head, T->bmin, T->bmax, T->range, T->export_buf, T->shard_order, T->shard_blk,
                     T->walk_counters, T->err_flag};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -782,6 +824,7 @@ void nb_tree_destroy(nbody_ctx* ctx) {
 
 int nb_tree_build(nbody_ctx* ctx, const float4* posm_in) {
     Octree* T = ctx->tree;
+    const MacScale mac = mac_scale(ctx);
     const uint32_t n = (uint32_t)T->n;
     const int D = (int)T->D;
     hipStream_t st = ctx->stream;
@@ -812,21 +855,21 @@ int nb_tree_build(nbody_ctx* ctx, const float4* posm_in) {
     if (r) return r;
     T->n_nodes = total;
     hipLaunchKernelGGL(k_emit, dim3(T->pf_nb), dim3(256), 0, st, T->keys[cur], T->idx[cur], posm_in, n, D, T->lo, T->top,
-                       T->flags, T->blk, T->pf_nb, T->lvl_start, T->nodes, T->bmin, T->bmax, T->node_head, T->body_node,
+                       T->flags, T->blk, T->pf_nb, T->lvl_start, T->nodes, T->bmin, T->bmax, T->range, T->node_head, T->body_node,
                        (uint32_t)T->cap_nodes, T->err_flag);
     NB_HIP(ctx, hipGetLastError());
     if (T->h_lvl_start[LIST_ROW + 1] > T->h_lvl_start[LIST_ROW] || T->h_lvl_start[D + 1] > T->h_lvl_start[D]) {
         hipLaunchKernelGGL(k_leaflist, dim3((n + 255) / 256), dim3(256), 0, st, T->keys[cur], T->idx[cur], posm_in, n,
-                           ctx->cfg.leaflist_mode, T->flags, T->body_node, T->nodes, T->bmin, T->bmax, T->node_head,
-                           (uint32_t)T->cap_nodes);
+                           ctx->cfg.leaflist_mode, T->flags, T->body_node, T->nodes, T->bmin, T->bmax, T->range, T->node_head,
+                           (uint32_t)T->cap_nodes, mac);
         NB_HIP(ctx, hipGetLastError());
     }
     for (int d = D - 1; d >= 0; --d) {
         const uint32_t first = T->h_lvl_start[d], count = T->h_lvl_start[d + 1] - first;
         if (!count) continue;
         // the children of level d are the nodes of level d + 1
-        hipLaunchKernelGGL(k_aggregate, dim3((count + 255) / 256), dim3(256), 0, st, T->nodes, T->bmin, T->bmax, first, count,
-                           T->h_lvl_start[d + 2]);
+        hipLaunchKernelGGL(k_aggregate, dim3((count + 255) / 256), dim3(256), 0, st, T->nodes, T->bmin, T->bmax, T->range, first,
+                           count, T->h_lvl_start[d + 2], mac);
     }
     NB_HIP(ctx, hipGetLastError());
     T->have_tree = true;
@@ -904,7 +947,7 @@ int nb_tree_device_nodes(nbody_ctx* ctx, void** ptr, size_t* bytes) {
     const uint32_t cnt = (uint32_t)T->n_nodes;
     if (!T->export_is_upload) {  // an uploaded tree is kept as it came (renumbered); a built one is exported
         hipLaunchKernelGGL(k_export, dim3((cnt + 255) / 256), dim3(256), 0, ctx->stream, T->nodes, T->bmin, T->bmax,
-                           T->node_head, T->keys[T->sorted], T->lvl_start, (int)T->D, cnt, T->export_buf);
+                           T->range, T->node_head, T->keys[T->sorted], T->lvl_start, (int)T->D, cnt, T->export_buf);
         NB_HIP(ctx, hipGetLastError());
     }
     *ptr = T->export_buf;
@@ -970,7 +1013,7 @@ int nb_tree_upload(nbody_ctx* ctx, const nbody_octree_node* host_nodes, uint64_t
     NB_HIP(ctx, hipMemcpyAsync(T->export_buf, renum.data(), kept * sizeof(nbody_octree_node), hipMemcpyHostToDevice, ctx->stream));
     const uint32_t cnt = (uint32_t)kept;
     hipLaunchKernelGGL(k_import, dim3((cnt + 255) / 256), dim3(256), 0, ctx->stream, T->export_buf, cnt, T->nodes, T->bmin,
-                       T->bmax, T->err_flag);
+                       T->bmax, T->range, mac_scale(ctx), T->err_flag);
     NB_HIP(ctx, hipGetLastError());
     NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     T->n_nodes = kept;

@@ -603,6 +603,21 @@ constexpr bool WALK_PRECISE = false;  // one Newton step on v_rsq_f32 in the tra
 constexpr int WALK_STACK = 160;  // >= 8 pushes per level x 17 levels + root
 constexpr int WALK_BATCH = 4;    // node records fetched together; the node array is padded by as many
 
+// The lanes for which p holds, as a wave-uniform value the compiler keeps in scalar registers
+// (without the empty asm it folds "ballot != 0" back into a per-lane test).
+__device__ __forceinline__ unsigned long long lanes(bool p) {
+    unsigned long long m = __ballot(p);
+    asm volatile("" : "+s"(m));
+    return m;
+}
+
+// Holds the traversal until a fetched record has arrived, so that the fetches of a batch are
+// all issued before the first record is looked at.
+__device__ __forceinline__ void pin_record(const QNode& nd) {
+    asm volatile("" ::"s"(nd.cx), "s"(nd.cy), "s"(nd.cz), "s"(nd.mass), "s"(nd.r2_open), "s"(nd.r2_accept), "s"(nd.first),
+                 "s"(nd.count_type));
+}
+
 template <int LAW, bool COUNT>
 __global__ __launch_bounds__(256) void k_walk(const QNode* __restrict__ q, const uint32_t* __restrict__ order, uint32_t m,
                                               uint32_t i_begin, const float4* __restrict__ posm,
@@ -645,14 +660,16 @@ __global__ __launch_bounds__(256) void k_walk(const QNode* __restrict__ q, const
         const uint32_t mlo = (uint32_t)__builtin_amdgcn_readfirstlane(e.z);
         const uint32_t mhi = (uint32_t)__builtin_amdgcn_readfirstlane(e.w);
         const unsigned long long mask = ((unsigned long long)mhi << 32) | (unsigned long long)mlo;
-        const bool active = (mask >> lane) & 1ull;
         for (uint32_t b0 = 0; b0 < cnt; b0 += WALK_BATCH) {
             const uint32_t nb = min((uint32_t)WALK_BATCH, cnt - b0);
             // All records of the batch are fetched before the first use, from consecutive
             // addresses whether the group has that many or not (the array is padded).
             QNode c[WALK_BATCH];
+            const QNode* group = q + (first + b0);
 #pragma unroll
-            for (int k = 0; k < WALK_BATCH; ++k) c[k] = q[first + b0 + k];
+            for (int k = 0; k < WALK_BATCH; ++k) c[k] = group[k];
+#pragma unroll
+            for (int k = 0; k < WALK_BATCH; ++k) pin_record(c[k]);
             if (top + WALK_BATCH > WALK_STACK) {
                 if (lane == 0) *err_flag = 2;
                 top = 0;
@@ -664,38 +681,39 @@ __global__ __launch_bounds__(256) void k_walk(const QNode* __restrict__ q, const
                 const QNode nd = c[k];
                 if (COUNT) {
                     n_wave += (lane == 0);
-                    n_visit += active;
+                    n_visit += __builtin_amdgcn_inverse_ballot_w64(mask);
                 }
                 const float dx = nd.cx - t.x, dy = nd.cy - t.y, dz = nd.cz - t.z;
                 const float r2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
-                bool take = active;  // LEAFBODY: a direct interaction (src/nbodybh.wgsl:76-102)
+                // lanes that take this node as one source; LEAFBODY: all of the group's
+                // (a direct interaction, src/nbodybh.wgsl:76-102)
+                unsigned long long take = mask;
                 if (qn_type(nd) != NBODY_NODE_LEAFBODY) {
                     // src/nbodybh.wgsl:104-106 by the node's squared-distance thresholds; the
                     // reference's own expression decides inside the band between them
-                    bool accept = r2 > nd.r2_accept;
-                    const bool unsure = !accept && !(r2 < nd.r2_open);
-                    if (__ballot(active && unsure) != 0ull) {
+                    const unsigned long long far = lanes(r2 > nd.r2_accept), near = lanes(r2 < nd.r2_open);
+                    take = mask & far;
+                    const unsigned long long unsure = mask & ~(far | near);
+                    if (unsure) {
                         const float rg = range[first + b0 + k];
                         const float rr = sqrtf(((dx * dx) + (dy * dy)) + (dz * dz));  // distance(pos, com)
-                        const bool exact = (rg / rr) < theta;
-                        accept = unsure ? exact : accept;
+                        take |= unsure & lanes((rg / rr) < theta);
                     }
-                    take = active && accept;
-                    const unsigned long long open = __ballot(active && !accept);
+                    const unsigned long long open = mask & ~take;
                     if (open) {
                         // INTERIOR: its children; LEAFLIST: its members (LEAFBODY records, src/nbodybh.wgsl:137-146)
                         stack[top] = make_uint4(nd.first, qn_count(nd), (uint32_t)open, (uint32_t)(open >> 32));
                         ++top;
                         if (COUNT) max_top = max(max_top, (uint32_t)top);
                     }
-                    if (COUNT) n_agg += take;
+                    if (COUNT) n_agg += __builtin_amdgcn_inverse_ballot_w64(take);
                 } else if (COUNT) {
-                    n_leaf += take;
+                    n_leaf += __builtin_amdgcn_inverse_ballot_w64(take);
                 }
-                if (__ballot(take) != 0ull) {
+                if (take) {
                     // every lane evaluates the term; lanes that do not take it add zero
                     const float sc = pair_scale<LAW, WALK_PRECISE>(t, dx, dy, dz, r2, nd.mass, eps2);
-                    const float w = take ? sc : 0.0f;
+                    const float w = __builtin_amdgcn_inverse_ballot_w64(take) ? sc : 0.0f;
                     ax = fmaf(w, dx, ax);
                     ay = fmaf(w, dy, ay);
                     az = fmaf(w, dz, az);

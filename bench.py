@@ -167,16 +167,17 @@ def main():
                                 "frac": wach / PEAK_FP32_TFLOPS, "steps": wsteps}
 
     def bh_leg(nbodies, bsteps):
-        """Barnes-Hut step (replicated octree build + traversal of this rank's targets + integrate/clamp
-        + all-gather of the positions), theta = 0.5, depth cap 16, targets sharded over the ranks."""
+        """Barnes-Hut step, theta = 0.5, depth cap 16.  With several GPUs every rank holds all bodies:
+        replicated octree build, traversal of this rank's run of the sorted (Morton) order,
+        all-gather of the accelerations (16 B/body), integration + clamp of all bodies."""
         m_, p_, v_ = (masses, pos, vel) if nbodies == n else nb.gen_plummer(nbodies, seed=42)
         b_, c_ = shard_range(nbodies, rank, world)
-        be = HipShardBackend(nbodies, b_, c_, local_rank, law=nb.LAW_PLUMMER)
+        be = HipShardBackend(nbodies, b_, c_, local_rank, law=nb.LAW_PLUMMER, bh_ranked=True)
         be.upload(m_, p_, v_)
         sim = ShardedSim(be, nbodies, rank, world)
         sim.step_bh(2)
         be.sim.set_counting(True)
-        be.sim.accel_bh()          # counting build of the traversal kernel, own targets only
+        be.sim.bh_forces_ranked(b_, c_)   # counting build of the traversal kernel, own targets only
         c = be.sim.counters()
         be.sim.set_counting(False)
         be.sim.set_kernel_timing(True)
@@ -187,6 +188,15 @@ def main():
         barrier()
         bdt = time.perf_counter() - t0
         wms, _ = be.sim.kernel_time(bh=True)
+        same = True
+        if world > 1:   # replicated state: every rank must have computed the same positions
+            with torch.cuda.stream(be.torch_stream):
+                cs = be.posm().to(torch.float64).sum().reshape(1)
+            torch.cuda.synchronize()
+            lo, hi = cs.clone(), cs.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            same = bool(lo.item() == hi.item()) and bool(torch.isfinite(cs).item())
         be.sim.close()
         tot = torch.tensor([c["bh_leaf_interactions"] + c["bh_aggregate_interactions"], c["bh_node_visits"],
                             c["bh_wave_node_visits"]], device="cuda", dtype=torch.float64)
@@ -198,7 +208,7 @@ def main():
         bdt, wms = float(mx[0]), float(mx[1])
         # bytes the traversal asks for: 32 B per wavefront node visit + per-body reads/writes
         walk_bytes = (32.0 * wave_visits + nbodies * (16 + 16 + 16)) / world
-        return {"n_bodies": nbodies, "n_gpus": world, "theta": 0.5, "max_depth": 16, "steps": bsteps,
+        return {"n_bodies": nbodies, "n_gpus": world, "ranks_hold_identical_positions": same, "theta": 0.5, "max_depth": 16, "steps": bsteps,
                 "steps_per_s": bsteps / bdt, "ms_per_step": bdt / bsteps * 1e3, "walk_kernel_ms": wms,
                 "octree_nodes": c["octree_nodes"], "interactions_per_step": inter,
                 "interactions_per_s": inter * bsteps / bdt, "node_visits_per_body": visits / nbodies,

@@ -103,7 +103,8 @@ enum nbody_buffer {
     NBODY_BUF_VEL = 1,   /* current velocities f32[N][4] */
     NBODY_BUF_ACC = 2,   /* current accelerations f32[N][4] */
     NBODY_BUF_OCTREE = 3, /* nbody_octree_node[n_nodes], exported on request */
-    NBODY_BUF_ACC_PARTIAL = 4 /* f32[N][4] written by nbody_allpairs_partial, read by nbody_integrate_partial */
+    NBODY_BUF_ACC_PARTIAL = 4 /* f32[N][4] exchanged between GPUs: written by nbody_allpairs_partial (read by
+                                 nbody_integrate_partial) or by nbody_bh_forces_ranked (read by nbody_integrate_ranked) */
 };
 
 /* Work done since nbody_create or the last nbody_counters_reset; for roofline arithmetic. */
@@ -155,6 +156,18 @@ int nbody_step_bh(nbody_ctx* ctx, int nsteps);
  * NBODY_BUF_POSM as after nbody_step_allpairs.  No counterpart in the reference (single device). */
 int nbody_allpairs_partial(nbody_ctx* ctx, uint32_t part, uint32_t nparts);
 int nbody_integrate_partial(nbody_ctx* ctx);
+
+/* Multi-GPU Barnes-Hut with REPLICATED state: every GPU holds all N bodies (a context without a
+ * shard range) and builds the same octree; the traversal is split by SORTED RANK, so that each
+ * GPU walks a spatially compact run of the Morton order (src/nbodybh.wgsl:63-161 per target).
+ * nbody_bh_forces_ranked builds the octree from the current positions and writes the
+ * accelerations of the bodies at ranks [rank_begin, rank_begin + rank_count) to
+ * NBODY_BUF_ACC_PARTIAL[rank].  The host all-gathers that buffer (16 bytes per body); then
+ * nbody_integrate_ranked brings it back to body order and advances ALL bodies (integration with
+ * clamp, src/nbodybh.wgsl:163-169) and swaps the sets.  Every GPU computes bit-identical states,
+ * so positions need no exchange.  No counterpart in the reference (single device). */
+int nbody_bh_forces_ranked(nbody_ctx* ctx, uint64_t rank_begin, uint64_t rank_count);
+int nbody_integrate_ranked(nbody_ctx* ctx);
 
 /* Forces only (no integration, no swap), for parity checks against src/nbody.wgsl:50-116 and
  * src/nbodybh.wgsl:63-161.  host_acc16_out is f32[N][4]; only this context's targets are written. */

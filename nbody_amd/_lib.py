@@ -61,6 +61,8 @@ SYMBOLS = {
     "nbody_step_bh": (C.c_int, [_P, C.c_int]),
     "nbody_allpairs_partial": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
     "nbody_integrate_partial": (C.c_int, [_P]),
+    "nbody_bh_forces_ranked": (C.c_int, [_P, C.c_uint64, C.c_uint64]),
+    "nbody_integrate_ranked": (C.c_int, [_P]),
     "nbody_accel_allpairs": (C.c_int, [_P, _P]),
     "nbody_accel_bh": (C.c_int, [_P, _P]),
     "nbody_build_octree": (C.c_int, [_P]),

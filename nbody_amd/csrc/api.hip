@@ -196,6 +196,7 @@ void nbody_destroy(nbody_ctx* ctx) {
     }
     if (ctx->acc_tmp) hipFree(ctx->acc_tmp);
     if (ctx->acc_part) hipFree(ctx->acc_part);
+    if (ctx->acc_body) hipFree(ctx->acc_body);
     if (ctx->masses) hipFree(ctx->masses);
     if (ctx->energy_dev) hipFree(ctx->energy_dev);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
@@ -289,6 +290,38 @@ int nbody_step_bh(nbody_ctx* ctx, int nsteps) {
         if (r) return r;
         ctx->counters.steps_bh += 1;
     }
+    return NBODY_OK;
+}
+
+int nbody_bh_forces_ranked(nbody_ctx* ctx, uint64_t rank_begin, uint64_t rank_count) {
+    if (!ctx) return NBODY_ERR_INVALID;
+    if (!ctx->uploaded) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_bh_forces_ranked: no bodies uploaded");
+    if (ctx->cfg.law == NBODY_LAW_CPU_R6)
+        return nb_fail(ctx, NBODY_ERR_INVALID, "the Barnes-Hut path uses the WGSL laws (src/nbodybh.wgsl), not CPU_R6");
+    if (ctx->i_count != ctx->n)
+        return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_bh_forces_ranked: the context must hold all bodies (no shard range)");
+    if (rank_begin > ctx->n || rank_count > ctx->n - rank_begin)
+        return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_bh_forces_ranked: rank range outside the bodies");
+    int r = set_device(ctx);
+    if (r) return r;
+    r = nb_tree_build(ctx, ctx->posm[ctx->cur]);
+    if (r) return r;
+    return nb_tree_walk_ranked(ctx, ctx->posm[ctx->cur], ctx->vel[ctx->cur], ctx->acc_tmp, rank_begin, rank_count);
+}
+
+int nbody_integrate_ranked(nbody_ctx* ctx) {
+    if (!ctx) return NBODY_ERR_INVALID;
+    if (!ctx->uploaded) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_integrate_ranked: no bodies uploaded");
+    if (ctx->i_count != ctx->n)
+        return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_integrate_ranked: the context must hold all bodies (no shard range)");
+    int r = set_device(ctx);
+    if (r) return r;
+    if (!ctx->acc_body) NB_HIP(ctx, hipMalloc(&ctx->acc_body, ctx->n * sizeof(float4)));
+    r = nb_tree_unrank(ctx, ctx->acc_tmp, ctx->acc_body);
+    if (r) return r;
+    r = nb_integrate_clamped(ctx, ctx->acc_body);
+    if (r) return r;
+    ctx->counters.steps_bh += 1;
     return NBODY_OK;
 }
 

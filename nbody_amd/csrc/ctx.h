@@ -34,6 +34,7 @@ struct nbody_ctx {
     float4* acc_part = nullptr;
     uint64_t acc_part_slices = 0;
     float4* acc_tmp = nullptr;  // [n] forces-only output / finalize target
+    float4* acc_body = nullptr; // [n] accelerations brought back from sorted-rank to body order (lazily allocated)
 
     // Octree state (octree.hip)
     struct Octree* tree = nullptr;
@@ -95,6 +96,9 @@ int nb_tree_create(nbody_ctx* ctx);
 void nb_tree_destroy(nbody_ctx* ctx);
 int nb_tree_build(nbody_ctx* ctx, const float4* posm_in);
 int nb_tree_walk(nbody_ctx* ctx, const float4* posm_in, const float4* vel_in, float4* acc_out);
+int nb_tree_walk_ranked(nbody_ctx* ctx, const float4* posm_in, const float4* vel_in, float4* acc_ranked, uint64_t rank_begin,
+                        uint64_t rank_count);
+int nb_tree_unrank(nbody_ctx* ctx, const float4* acc_ranked, float4* acc_out);
 int nb_tree_download(nbody_ctx* ctx, nbody_octree_node* host_nodes, uint64_t cap, uint64_t* n_nodes);
 int nb_tree_upload(nbody_ctx* ctx, const nbody_octree_node* host_nodes, uint64_t n_nodes);
 int nb_tree_keys(nbody_ctx* ctx, uint64_t* keys, uint8_t* depth, uint32_t* order);

@@ -548,6 +548,12 @@ __global__ void k_import(const nbody_octree_node* __restrict__ in, uint32_t coun
 
 // Body indices of the sorted order restricted to [i_begin, i_end): stable compaction, one
 // workgroup (the shard lists are rebuilt once per step; n / 1024 trips).
+__global__ void k_unrank(const uint32_t* __restrict__ order, const float4* __restrict__ by_rank, uint32_t n,
+                         float4* __restrict__ by_body) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) by_body[order[r]] = by_rank[r];
+}
+
 constexpr int CO_ITEMS = 16, CO_TILE = 256 * CO_ITEMS;
 
 __global__ __launch_bounds__(256) void k_compact_count(const uint32_t* __restrict__ idx, uint32_t n, uint32_t i_begin,
@@ -601,7 +607,7 @@ __global__ __launch_bounds__(256) void k_compact_scatter(const uint32_t* __restr
 // children are fetched together when it is popped.
 constexpr bool WALK_PRECISE = false;  // one Newton step on v_rsq_f32 in the traversal's interactions
 constexpr int WALK_STACK = 160;  // >= 8 pushes per level x 17 levels + root
-constexpr int WALK_BATCH = 4;    // node records fetched together; the node array is padded by as many
+constexpr int WALK_BATCH = 8;    // node records fetched together; the node array is padded by as many
 
 // The lanes for which p holds, as a wave-uniform value the compiler keeps in scalar registers
 // (without the empty asm it folds "ballot != 0" back into a per-lane test).
@@ -624,7 +630,9 @@ __global__ __launch_bounds__(256) void k_walk(const QNode* __restrict__ q, const
                                               const float4* __restrict__ vel, float4* __restrict__ acc_out, float G,
                                               float eps2, float theta, const float* __restrict__ range,
                                               unsigned long long* __restrict__ counters,
-                                              uint32_t* __restrict__ err_flag) {
+                                              uint32_t* __restrict__ err_flag, int out_by_rank) {
+    // Target r of this launch is body order[r] (or i_begin + r without an order); its result goes
+    // to acc_out[body], or with out_by_rank to acc_out[i_begin + r].
     __shared__ uint4 st[4][WALK_STACK];  // {first, count, mask.lo, mask.hi}
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t r = blockIdx.x * 256 + tid;
@@ -721,7 +729,7 @@ __global__ __launch_bounds__(256) void k_walk(const QNode* __restrict__ q, const
             }
         }
     }
-    if (valid) acc_out[b] = make_float4(G * ax, G * ay, G * az, 0.0f);
+    if (valid) acc_out[out_by_rank ? i_begin + r : b] = make_float4(G * ax, G * ay, G * az, 0.0f);
     if (COUNT) {
         atomicAdd(&counters[0], (unsigned long long)n_visit);
         atomicAdd(&counters[1], (unsigned long long)n_leaf);
@@ -778,16 +786,16 @@ int check_err_flag(nbody_ctx* ctx, Octree* T, const char* what) {
 
 template <int LAW>
 void launch_walk(nbody_ctx* ctx, Octree* T, const uint32_t* order, uint32_t m, const float4* posm, const float4* vel,
-                 float4* acc_out) {
+                 float4* acc_out, uint32_t i_begin, int out_by_rank) {
     dim3 grid((m + 255) / 256);
     if (ctx->counting)
-        hipLaunchKernelGGL((k_walk<LAW, true>), grid, dim3(256), 0, ctx->stream, T->nodes, order, m, (uint32_t)ctx->i_begin,
+        hipLaunchKernelGGL((k_walk<LAW, true>), grid, dim3(256), 0, ctx->stream, T->nodes, order, m, i_begin,
                            posm, vel, acc_out, ctx->cfg.G, ctx->cfg.eps2, ctx->cfg.theta, T->range,
-                           (unsigned long long*)T->walk_counters, T->err_flag);
+                           (unsigned long long*)T->walk_counters, T->err_flag, out_by_rank);
     else
-        hipLaunchKernelGGL((k_walk<LAW, false>), grid, dim3(256), 0, ctx->stream, T->nodes, order, m, (uint32_t)ctx->i_begin,
+        hipLaunchKernelGGL((k_walk<LAW, false>), grid, dim3(256), 0, ctx->stream, T->nodes, order, m, i_begin,
                            posm, vel, acc_out, ctx->cfg.G, ctx->cfg.eps2, ctx->cfg.theta, T->range,
-                           (unsigned long long*)T->walk_counters, T->err_flag);
+                           (unsigned long long*)T->walk_counters, T->err_flag, out_by_rank);
 }
 
 }  // namespace
@@ -897,6 +905,31 @@ int nb_tree_build(nbody_ctx* ctx, const float4* posm_in) {
     return NBODY_OK;
 }
 
+static int walk_launch(nbody_ctx* ctx, Octree* T, const uint32_t* order, uint32_t m, const float4* posm_in,
+                       const float4* vel_in, float4* acc_out, uint32_t i_begin, int out_by_rank) {
+    hipStream_t st = ctx->stream;
+    if (ctx->counting) NB_HIP(ctx, hipMemsetAsync(T->walk_counters, 0, 8 * sizeof(uint64_t), st));
+    nb_time_begin(ctx, 1);
+    if (ctx->cfg.law == NBODY_LAW_WGSL_BIAS)
+        launch_walk<NBODY_LAW_WGSL_BIAS>(ctx, T, order, m, posm_in, vel_in, acc_out, i_begin, out_by_rank);
+    else
+        launch_walk<NBODY_LAW_PLUMMER>(ctx, T, order, m, posm_in, vel_in, acc_out, i_begin, out_by_rank);
+    nb_time_end(ctx, 1);
+    NB_HIP(ctx, hipGetLastError());
+    if (ctx->counting) {
+        uint64_t h[8];
+        NB_HIP(ctx, hipMemcpyAsync(h, T->walk_counters, sizeof h, hipMemcpyDeviceToHost, st));
+        NB_HIP(ctx, hipStreamSynchronize(st));
+        ctx->counters.bh_node_visits = h[0];
+        ctx->counters.bh_leaf_interactions = h[1];
+        ctx->counters.bh_aggregate_interactions = h[2];
+        ctx->counters.bh_wave_node_visits = h[3];
+        ctx->counters.bh_max_stack = h[4];
+        return check_err_flag(ctx, T, "traversal");
+    }
+    return NBODY_OK;
+}
+
 int nb_tree_walk(nbody_ctx* ctx, const float4* posm_in, const float4* vel_in, float4* acc_out) {
     Octree* T = ctx->tree;
     if (!T->have_tree) return nb_fail(ctx, NBODY_ERR_STATE, "no octree: call nbody_build_octree or nbody_upload_octree first");
@@ -916,23 +949,28 @@ int nb_tree_walk(nbody_ctx* ctx, const float4* posm_in, const float4* vel_in, fl
             order = T->shard_order;
         }
     }
-    if (ctx->counting) NB_HIP(ctx, hipMemsetAsync(T->walk_counters, 0, 8 * sizeof(uint64_t), st));
-    nb_time_begin(ctx, 1);
-    if (ctx->cfg.law == NBODY_LAW_WGSL_BIAS) launch_walk<NBODY_LAW_WGSL_BIAS>(ctx, T, order, m, posm_in, vel_in, acc_out);
-    else launch_walk<NBODY_LAW_PLUMMER>(ctx, T, order, m, posm_in, vel_in, acc_out);
-    nb_time_end(ctx, 1);
+    return walk_launch(ctx, T, order, m, posm_in, vel_in, acc_out, (uint32_t)ctx->i_begin, 0);
+}
+
+// Targets = the bodies at sorted ranks [rank_begin, rank_begin + rank_count) of the built tree;
+// acc_ranked[rank] receives their accelerations.
+int nb_tree_walk_ranked(nbody_ctx* ctx, const float4* posm_in, const float4* vel_in, float4* acc_ranked,
+                        uint64_t rank_begin, uint64_t rank_count) {
+    Octree* T = ctx->tree;
+    if (!T->have_tree || !T->built) return nb_fail(ctx, NBODY_ERR_STATE, "ranked traversal needs an octree built from the bodies");
+    if (rank_begin + rank_count > T->n) return nb_fail(ctx, NBODY_ERR_INVALID, "rank range outside the bodies");
+    if (rank_count == 0) return NBODY_OK;
+    return walk_launch(ctx, T, T->idx[T->sorted] + rank_begin, (uint32_t)rank_count, posm_in, vel_in, acc_ranked,
+                       (uint32_t)rank_begin, 1);
+}
+
+// acc_out[body at rank r] = acc_ranked[r] for every rank of the built tree.
+int nb_tree_unrank(nbody_ctx* ctx, const float4* acc_ranked, float4* acc_out) {
+    Octree* T = ctx->tree;
+    if (!T->have_tree || !T->built) return nb_fail(ctx, NBODY_ERR_STATE, "no octree built from the bodies");
+    const uint32_t n = (uint32_t)T->n;
+    hipLaunchKernelGGL(k_unrank, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, T->idx[T->sorted], acc_ranked, n, acc_out);
     NB_HIP(ctx, hipGetLastError());
-    if (ctx->counting) {
-        uint64_t h[8];
-        NB_HIP(ctx, hipMemcpyAsync(h, T->walk_counters, sizeof h, hipMemcpyDeviceToHost, st));
-        NB_HIP(ctx, hipStreamSynchronize(st));
-        ctx->counters.bh_node_visits = h[0];
-        ctx->counters.bh_leaf_interactions = h[1];
-        ctx->counters.bh_aggregate_interactions = h[2];
-        ctx->counters.bh_wave_node_visits = h[3];
-        ctx->counters.bh_max_stack = h[4];
-        return check_err_flag(ctx, T, "traversal");
-    }
     return NBODY_OK;
 }
 

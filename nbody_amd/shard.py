@@ -4,8 +4,14 @@ The reference is single-device.  Here the targets are split into contiguous equa
 per rank; every rank integrates its own bodies against ALL sources, then the ranks all-gather
 the packed {x,y,z,m} positions (16 bytes per body) so that each holds the sources of the next
 step.  Velocities and accelerations never leave their rank: the force laws only need the
-target's own velocity (src/nbody.wgsl:74-76).  For Barnes-Hut every rank rebuilds the same
-(replicated) octree from the gathered positions and walks only its own range.
+target's own velocity (src/nbody.wgsl:74-76).  
+Barnes-Hut uses REPLICATED state instead (`HipShardBackend(..., bh_ranked=True)`): every rank
+holds all N bodies and builds the same octree; rank r traverses the r-th run of the SORTED
+(Morton) order, a spatially compact set of targets whose lanes share their tree paths; the ranks
+all-gather the accelerations in sorted order (16 bytes per body, the same volume as positions
+would be) and every rank integrates all bodies, reaching bit-identical states.  Splitting the
+traversal by body index instead (the all-pairs split) costs 1.7x more traversal time per rank at
+8 ranks, because a rank's 64-lane groups then span 8x the volume.
 
 The exchange is one collective per step (`all_gather_into_tensor`, RCCL over xGMI on GPUs); the
 compute backend is injected so that the exchange logic can be exercised with gloo on CPU.
@@ -43,9 +49,15 @@ class HipShardBackend:
 
     PAIR_SHARD_MIN_N = 65536
 
-    def __init__(self, n, begin, count, device_index, **cfg):
+    def __init__(self, n, begin, count, device_index, bh_ranked=False, **cfg):
         from .sim import NBodySim, BUF_POSM, BUF_ACC_PARTIAL, LAW_PLUMMER, INT_WGSL_VERLET
         torch.cuda.set_device(device_index)
+        self.bh_ranked = bh_ranked
+        self.begin, self.count = begin, count
+        if bh_ranked:  # replicated state: the context holds (and integrates) all bodies
+            cfg = dict(cfg, shard_begin=0, shard_count=n)
+        else:
+            cfg = dict(cfg, shard_begin=begin, shard_count=count)
         self._buf_posm = BUF_POSM
         self._buf_partial = BUF_ACC_PARTIAL
         self.pair_sharding = (cfg.get("law") == LAW_PLUMMER and cfg.get("integrator", INT_WGSL_VERLET) == INT_WGSL_VERLET
@@ -54,8 +66,7 @@ class HipShardBackend:
         # dependencies.  (A null stream handle would not do: the library takes it as "create a
         # stream of your own", which torch then knows nothing about.)
         self.torch_stream = torch.cuda.Stream(device=device_index)
-        self.sim = NBodySim(n, shard_begin=begin, shard_count=count, device=device_index,
-                            stream=self.torch_stream.cuda_stream, **cfg)
+        self.sim = NBodySim(n, device=device_index, stream=self.torch_stream.cuda_stream, **cfg)
         self.n = n
         self._views = {}
 
@@ -82,6 +93,12 @@ class HipShardBackend:
 
     def integrate_partial(self):
         self.sim.integrate_partial()
+
+    def bh_forces_ranked(self):
+        self.sim.bh_forces_ranked(self.begin, self.count)
+
+    def integrate_ranked(self):
+        self.sim.integrate_ranked()
 
     def download(self):
         return self.sim.download()
@@ -113,7 +130,10 @@ class ShardedSim:
             self._exchange()
 
     def _exchange(self):
-        full = self.backend.posm()
+        self._gather_ranges(self.backend.posm())
+
+    def _gather_ranges(self, full):
+        """full[begin_r : begin_r + count_r] of every rank r reaches all ranks (in place)."""
         if self.n % self.world == 0:
             # a private copy of the own range (16 B/body): input and output never alias
             own = full[self.begin:self.begin + self.count].clone()
@@ -160,6 +180,13 @@ class ShardedSim:
             self.exchange()
 
     def step_bh(self, nsteps=1):
+        ranked = getattr(self.backend, "bh_ranked", False)
         for _ in range(nsteps):
-            self.backend.step("bh")
-            self.exchange()
+            if ranked and self.world > 1:
+                self.backend.bh_forces_ranked()
+                with self._stream():
+                    self._gather_ranges(self.backend.acc_partial())
+                self.backend.integrate_ranked()
+            else:
+                self.backend.step("bh")
+                self.exchange()

@@ -143,6 +143,15 @@ class NBodySim:
     def integrate_partial(self):
         self._ck(self.lib.nbody_integrate_partial(self.h))
 
+    def bh_forces_ranked(self, rank_begin, rank_count):
+        """Octree build + traversal for the bodies at sorted ranks [rank_begin, rank_begin + rank_count):
+        accelerations to BUF_ACC_PARTIAL[rank]."""
+        self._ck(self.lib.nbody_bh_forces_ranked(self.h, rank_begin, rank_count))
+
+    def integrate_ranked(self):
+        """BUF_ACC_PARTIAL (by sorted rank, all N) -> body order, integrate + clamp all bodies, swap."""
+        self._ck(self.lib.nbody_integrate_ranked(self.h))
+
     def accel_allpairs(self):
         a = np.zeros((self.n, 4), np.float32)
         self._ck(self.lib.nbody_accel_allpairs(self.h, _ptr(a)))

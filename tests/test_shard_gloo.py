@@ -20,10 +20,11 @@ if ROOT not in sys.path:
 class OracleShardBackend:
     """Test stand-in for HipShardBackend: same interface, oracle arithmetic on host tensors."""
 
-    def __init__(self, n, begin, count, law, pair_sharding=False):
+    def __init__(self, n, begin, count, law, pair_sharding=False, bh_ranked=False):
         from oracle import oracle as orc
         self.orc, self.n, self.b, self.c, self.law = orc, n, begin, count, law
         self.pair_sharding = pair_sharding
+        self.bh_ranked = bh_ranked
         self.partial = torch.zeros(n, 4)
         self.full = torch.zeros(n, 4)          # packed {x,y,z,m}: the buffer the ranks all-gather
         self.vel = np.zeros((n, 4), np.float32)
@@ -66,6 +67,30 @@ class OracleShardBackend:
         f[s, :3] = po[:, :3]
         self.vel[s], self.acc[s] = vo, ao
 
+    # replicated-state Barnes-Hut: accelerations of the bodies at sorted ranks [b, b + c) into
+    # partial[rank]; after the all-gather every rank integrates ALL bodies
+    def bh_forces_ranked(self):
+        orc = self.orc
+        f = self.full.numpy()
+        pos = np.zeros((self.n, 4), np.float32)
+        pos[:, :3] = f[:, :3]
+        self.order = np.argsort(orc.morton_keys(pos), kind="stable")
+        nodes, _, _, _ = orc.build_octree(pos, self.m)
+        a, _ = orc.bh_accel(self.law, pos, self.vel, nodes)
+        own = slice(self.b, self.b + self.c)
+        self.partial.numpy()[own] = a[self.order[own]]
+
+    def integrate_ranked(self):
+        orc = self.orc
+        f = self.full.numpy()
+        pos = np.zeros((self.n, 4), np.float32)
+        pos[:, :3] = f[:, :3]
+        a = np.zeros((self.n, 4), np.float32)
+        a[self.order] = self.partial.numpy()
+        po, vo, ao = orc.integrate_wgsl(pos, self.vel, self.acc, a, clamp_world=250.0)
+        f[:, :3] = po[:, :3]
+        self.vel[:], self.acc[:] = vo, ao
+
     def step(self, kind):
         orc, b, c = self.orc, self.b, self.c
         f = self.full.numpy()
@@ -90,7 +115,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, law, kind, steps, out_dir, pair=False):
+def _worker(rank, world, port, n, law, kind, steps, out_dir, pair=False, ranked=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, ROOT)
@@ -104,7 +129,7 @@ def _worker(rank, world, port, n, law, kind, steps, out_dir, pair=False):
         vel = np.zeros((n, 4), np.float32)
         vel[:, :3] = 0.2 * (orc.gen_refcube(n, seed=9)[1][:, :3] / 125.0 - 1.0)
         b, c = shard_range(n, rank, world)
-        be = OracleShardBackend(n, b, c, law, pair_sharding=pair)
+        be = OracleShardBackend(n, b, c, law, pair_sharding=pair, bh_ranked=ranked)
         be.upload(m, pos, vel)
         sim = ShardedSim(be, n)
         assert (sim.begin, sim.count) == (b, c)
@@ -115,9 +140,9 @@ def _worker(rank, world, port, n, law, kind, steps, out_dir, pair=False):
         dist.destroy_process_group()
 
 
-def _run(world, n, law, kind, steps, tmp_path, pair=False):
+def _run(world, n, law, kind, steps, tmp_path, pair=False, ranked=False):
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, n, law, kind, steps, str(tmp_path), pair), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, n, law, kind, steps, str(tmp_path), pair, ranked), nprocs=world, join=True)
     from nbody_amd.shard import shard_range
     full = [np.load(tmp_path / f"posm_{r}.npy") for r in range(world)]
     vel = np.zeros((n, 4), np.float32)
@@ -160,6 +185,21 @@ def test_sharded_bh_equals_unsharded(orc, tmp_path):
     for f in full:
         assert np.array_equal(f[:, :3], rp[:, :3])
     assert np.array_equal(vel, rv)
+
+
+@pytest.mark.parametrize("world,n", [(2, 400), (3, 301)])
+def test_ranked_bh_equals_unsharded(orc, tmp_path, world, n):
+    """Replicated state, traversal split by sorted rank, accelerations all-gathered: every rank
+    ends with the unsharded run's state, bit for bit."""
+    steps, law = 2, orc.LAW_WGSL_BIAS
+    full, vel = _run(world, n, law, "bh", steps, tmp_path, ranked=True)
+    m, pos = orc.gen_refcube(n, seed=8)
+    v0 = np.zeros((n, 4), np.float32)
+    v0[:, :3] = 0.2 * (orc.gen_refcube(n, seed=9)[1][:, :3] / 125.0 - 1.0)
+    rp, rv, ra = orc.step_bh(law, m, pos, v0, np.zeros_like(pos), steps)
+    for f in full:
+        assert np.array_equal(f[:, :3], rp[:, :3])
+    assert np.array_equal(vel, rv)      # assembled from each rank's own slice of its replicated copy
 
 
 def test_pair_sharded_allpairs_matches_unsharded(orc, tmp_path):

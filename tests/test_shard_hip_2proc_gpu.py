@@ -34,15 +34,15 @@ os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[4])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 note("process group up")
 
-def run(n, law, kind, steps, dataset):
+def run(n, law, kind, steps, dataset, ranked=False):
     import time
     t0 = time.time()
     try:
-        return run_(n, law, kind, steps, dataset)
+        return run_(n, law, kind, steps, dataset, ranked)
     finally:
         note("case", n, law, kind, f"{time.time() - t0:.1f} s")
 
-def run_(n, law, kind, steps, dataset):
+def run_(n, law, kind, steps, dataset, ranked):
     m, pos, vel = dataset(n)
     ref = nb.NBodySim(n, law=law)
     ref.upload(m, pos, vel)
@@ -50,7 +50,7 @@ def run_(n, law, kind, steps, dataset):
     rp, rv, ra = ref.download()
     ref.close()
     b, c = shard_range(n, rank, world)
-    be = HipShardBackend(n, b, c, 0, law=law)
+    be = HipShardBackend(n, b, c, 0, law=law, bh_ranked=ranked)
     be.upload(m, pos, vel)
     sim = ShardedSim(be, n, rank, world)
     (sim.step_bh if kind == "bh" else sim.step_allpairs)(steps)
@@ -58,7 +58,7 @@ def run_(n, law, kind, steps, dataset):
     p, v, a = be.download()
     pair = be.pair_sharding and kind != "bh"
     be.sim.close()
-    own = slice(b, b + c)
+    own = slice(0, n) if ranked else slice(b, b + c)   # replicated state: every body is this rank's
     if kind != "bh":
         # the summation is split differently (launch shape follows the target count; pair tiles
         # are dealt over the ranks), so equality is to rounding
@@ -82,6 +82,8 @@ assert not run(8192, nb.LAW_PLUMMER, "allpairs", 3, plummer)       # below the p
 assert run(65536, nb.LAW_PLUMMER, "allpairs", 2, plummer)          # pair tiles dealt over the ranks
 assert not run(20000, nb.LAW_WGSL_BIAS, "bh", 3, refcube)          # replicated tree, sharded walk
 assert not run(30001, nb.LAW_PLUMMER, "bh", 3, plummer)
+assert not run(20000, nb.LAW_WGSL_BIAS, "bh", 3, refcube, ranked=True)   # replicated state, traversal split by sorted rank
+assert not run(30001, nb.LAW_PLUMMER, "bh", 3, plummer, ranked=True)
 dist.barrier()
 dist.destroy_process_group()
 print("RANK_OK", rank)

@@ -138,8 +138,10 @@ __global__ void k_morton(const float4* __restrict__ posm, uint32_t n, float worl
 
 // ---- 2. LSD radix sort, 8-bit digits ------------------------------------------------------
 constexpr int RS_THREADS = 256;
-constexpr int RS_ITEMS = 8;
-constexpr int RS_TILE = RS_THREADS * RS_ITEMS;
+constexpr int RS_WAVES = RS_THREADS / 64;
+constexpr int RS_ITEMS = 16;
+constexpr int RS_TILE = RS_THREADS * RS_ITEMS;  // items of one workgroup: wavefront w owns [w, w+1) * RS_TILE / RS_WAVES
+constexpr int RS_WTILE = RS_TILE / RS_WAVES;
 
 __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint64_t* __restrict__ keys, uint32_t n, int shift,
                                                         uint32_t* __restrict__ counts, uint32_t nb) {
@@ -216,32 +218,43 @@ __global__ __launch_bounds__(256) void k_scan_small(const uint32_t* __restrict__
     if (tid == 0 && rows == 256) out[256] = s[256];
 }
 
+// One tile: rank every item among the tile's items of the same digit (stable: wavefront-major,
+// then load order, then lane), stage the tile in LDS in digit order, then write each digit's run
+// to its place in the output with consecutive lanes on consecutive addresses.
 __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t* __restrict__ keys_in,
                                                            const uint32_t* __restrict__ idx_in,
                                                            uint64_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out,
                                                            uint32_t n, int shift, const uint32_t* __restrict__ counts,
                                                            const uint32_t* __restrict__ row_base, uint32_t nb) {
-    __shared__ uint32_t running[256];
-    __shared__ uint32_t wcnt[4][256];
+    __shared__ uint32_t wcnt[RS_WAVES][256];  // per-wavefront digit counts, then tile-local offsets
+    __shared__ uint32_t gbase[256];           // output position of staged item j of digit d = gbase[d] + j
+    __shared__ uint32_t wsum[RS_WAVES];
+    __shared__ uint64_t skey[RS_TILE];
+    __shared__ uint32_t sval[RS_TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    running[tid] = row_base[tid] + counts[(size_t)tid * nb + blockIdx.x];
-    const uint32_t base = blockIdx.x * RS_TILE;
+#pragma unroll
+    for (int w = 0; w < RS_WAVES; ++w) wcnt[w][tid] = 0;
+    __syncthreads();
+    const uint32_t tile0 = blockIdx.x * RS_TILE;
+    const uint32_t wbase = tile0 + wave * RS_WTILE;
     const unsigned long long lt = (1ull << lane) - 1ull;
+    uint64_t key[RS_ITEMS];
+    uint32_t val[RS_ITEMS], rnk[RS_ITEMS];
+#pragma unroll
     for (int it = 0; it < RS_ITEMS; ++it) {
-        const uint32_t i = base + it * RS_THREADS + tid;
-        const bool valid = i < n;
-        uint64_t key = 0;
-        uint32_t val = 0, d = 0;
-        if (valid) {
-            key = keys_in[i];
-            val = idx_in[i];
-            d = (uint32_t)(key >> shift) & 255u;
+        const uint32_t i = wbase + it * 64 + lane;
+        key[it] = 0;
+        val[it] = 0;
+        if (i < n) {
+            key[it] = keys_in[i];
+            val[it] = idx_in[i];
         }
-        wcnt[0][tid] = 0;
-        wcnt[1][tid] = 0;
-        wcnt[2][tid] = 0;
-        wcnt[3][tid] = 0;
-        __syncthreads();
+    }
+    volatile uint32_t* wc = wcnt[wave];  // this wavefront's counters: its LDS accesses stay in program order
+#pragma unroll
+    for (int it = 0; it < RS_ITEMS; ++it) {
+        const bool valid = wbase + it * 64 + lane < n;
+        const uint32_t d = (uint32_t)(key[it] >> shift) & 255u;
         // lanes of this wavefront holding the same digit
         unsigned long long peers = __ballot(valid);
 #pragma unroll
@@ -250,18 +263,61 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t* __res
             const unsigned long long m = __ballot(bit);
             peers &= bit ? m : ~m;
         }
-        const uint32_t rank = __popcll(peers & lt);
-        if (valid && rank == 0) wcnt[wave][d] = __popcll(peers);
-        __syncthreads();
-        if (valid) {
-            uint32_t pos = running[d] + rank;
-            for (int w = 0; w < wave; ++w) pos += wcnt[w][d];
-            keys_out[pos] = key;
-            idx_out[pos] = val;
+        const uint32_t r = __popcll(peers & lt);
+        const uint32_t prior = wc[d];
+        rnk[it] = prior + r;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (valid && r == 0) wc[d] = prior + (uint32_t)__popcll(peers);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    __syncthreads();
+    {
+        // thread d: the tile's count of digit d, its exclusive scan over the digits, and from
+        // that each wavefront's first staged slot for the digit
+        uint32_t c[RS_WAVES], tot = 0;
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; ++w) {
+            c[w] = wcnt[w][tid];
+            tot += c[w];
         }
+        uint32_t x = tot;  // inclusive scan over the wavefront
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
         __syncthreads();
-        running[tid] += wcnt[0][tid] + wcnt[1][tid] + wcnt[2][tid] + wcnt[3][tid];
-        __syncthreads();
+        uint32_t start = x - tot;
+        for (int w = 0; w < wave; ++w) start += wsum[w];
+        gbase[tid] = row_base[tid] + counts[(size_t)tid * nb + blockIdx.x] - start;
+        uint32_t o = start;
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; ++w) {
+            wcnt[w][tid] = o;
+            o += c[w];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < RS_ITEMS; ++it) {
+        if (wbase + it * 64 + lane < n) {
+            const uint32_t d = (uint32_t)(key[it] >> shift) & 255u;
+            const uint32_t slot = wcnt[wave][d] + rnk[it];
+            skey[slot] = key[it];
+            sval[slot] = val[it];
+        }
+    }
+    __syncthreads();
+    const uint32_t cnt = min((uint32_t)RS_TILE, n - tile0);
+    for (uint32_t j = tid; j < cnt; j += RS_THREADS) {
+        const uint64_t k = skey[j];
+        const uint32_t pos = gbase[(uint32_t)(k >> shift) & 255u] + j;
+        keys_out[pos] = k;
+        idx_out[pos] = sval[j];
     }
 }
 

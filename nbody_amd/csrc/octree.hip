@@ -80,12 +80,12 @@ struct Octree {
     uint32_t* rs_counts = nullptr;  // [256][rs_nb]
     uint32_t rs_nb = 0;
     uint32_t* row_total = nullptr;  // [256]
-    uint32_t* row_base = nullptr;   // [257]
     uint32_t* blk = nullptr;        // [NCNT][pf_nb]
     uint32_t pf_nb = 0;
     uint32_t* lvl_total = nullptr;  // [NCNT]
     uint32_t* lvl_start = nullptr;  // [NCNT+1]
-    uint32_t h_lvl_start[NCNT + 1] = {0};
+    uint32_t* h_lvl_start = nullptr;  // pinned host copy of lvl_start
+    hipEvent_t lvl_ready = nullptr;   // the copy into it has completed
     // nodes
     QNode* nodes = nullptr;
     float4* bmin = nullptr;          // bounding box of the bodies below each node
@@ -225,10 +225,10 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t* __res
                                                            const uint32_t* __restrict__ idx_in,
                                                            uint64_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out,
                                                            uint32_t n, int shift, const uint32_t* __restrict__ counts,
-                                                           const uint32_t* __restrict__ row_base, uint32_t nb) {
+                                                           const uint32_t* __restrict__ row_total, uint32_t nb) {
     __shared__ uint32_t wcnt[RS_WAVES][256];  // per-wavefront digit counts, then tile-local offsets
     __shared__ uint32_t gbase[256];           // output position of staged item j of digit d = gbase[d] + j
-    __shared__ uint32_t wsum[RS_WAVES];
+    __shared__ uint32_t wsum[RS_WAVES], gsum[RS_WAVES];
     __shared__ uint64_t skey[RS_TILE];
     __shared__ uint32_t sval[RS_TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -289,11 +289,25 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t* __res
             const uint32_t y = __shfl_up(x, o, 64);
             if (lane >= o) x += y;
         }
-        if (lane == 63) wsum[wave] = x;
+        // ... and the same scan over the digits' totals in the whole input: where digit d begins
+        const uint32_t gt = row_total[tid];
+        uint32_t gx = gt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(gx, o, 64);
+            if (lane >= o) gx += y;
+        }
+        if (lane == 63) {
+            wsum[wave] = x;
+            gsum[wave] = gx;
+        }
         __syncthreads();
-        uint32_t start = x - tot;
-        for (int w = 0; w < wave; ++w) start += wsum[w];
-        gbase[tid] = row_base[tid] + counts[(size_t)tid * nb + blockIdx.x] - start;
+        uint32_t start = x - tot, gstart = gx - gt;
+        for (int w = 0; w < wave; ++w) {
+            start += wsum[w];
+            gstart += gsum[w];
+        }
+        gbase[tid] = gstart + counts[(size_t)tid * nb + blockIdx.x] - start;
         uint32_t o = start;
 #pragma unroll
         for (int w = 0; w < RS_WAVES; ++w) {
@@ -431,9 +445,8 @@ __global__ __launch_bounds__(256) void k_emit(const uint64_t* __restrict__ keys,
                 nd.first = 0;
                 nd.count_type = qn_pack(0, type);
                 nodes[id] = nd;
-                range[id] = 0.0f;
-                bmin[id] = make_float4(p.x, p.y, p.z, 0.0f);
-                bmax[id] = make_float4(p.x, p.y, p.z, 0.0f);
+                // (a LEAFBODY's box is its position and its range 0: bmin/bmax/range hold entries
+                // for the other node types only)
                 node_head[id] = i;
                 if (d == t) body_node[i] = id;
                 pend = id;
@@ -469,9 +482,6 @@ __global__ void k_leaflist(const uint64_t* __restrict__ keys, const uint32_t* __
             c.first = 0;
             c.count_type = qn_pack(0, NBODY_NODE_LEAFBODY);
             nodes[member] = c;
-            range[member] = 0.0f;
-            bmin[member] = make_float4(q.x, q.y, q.z, 0.0f);
-            bmax[member] = make_float4(q.x, q.y, q.z, 0.0f);
             node_head[member] = i;
         }
         ++member;
@@ -519,7 +529,11 @@ __global__ void k_aggregate(QNode* __restrict__ nodes, float4* __restrict__ bmin
         wx += ch.cx * ch.mass;
         wy += ch.cy * ch.mass;
         wz += ch.cz * ch.mass;
-        const float4 lo = bmin[c], hi = bmax[c];
+        float4 lo = make_float4(ch.cx, ch.cy, ch.cz, 0.0f), hi = lo;
+        if (qn_type(ch) != NBODY_NODE_LEAFBODY) {
+            lo = bmin[c];
+            hi = bmax[c];
+        }
         mnx = fminf(mnx, lo.x); mny = fminf(mny, lo.y); mnz = fminf(mnz, lo.z);
         mxx = fmaxf(mxx, hi.x); mxy = fmaxf(mxy, hi.y); mxz = fmaxf(mxz, hi.z);
     }
@@ -543,14 +557,16 @@ __global__ void k_export(const QNode* __restrict__ nodes, const float4* __restri
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= count) return;
     const QNode nd = nodes[id];
-    const float4 lo = bmin[id], hi = bmax[id];
+    const bool leaf = qn_type(nd) == NBODY_NODE_LEAFBODY;  // its box is its position, its range 0
+    const float4 lo = leaf ? make_float4(nd.cx, nd.cy, nd.cz, 0.0f) : bmin[id];
+    const float4 hi = leaf ? make_float4(nd.cx, nd.cy, nd.cz, 0.0f) : bmax[id];
     int depth = 0;
     while (depth < D && id >= lvl_start[depth + 1]) ++depth;  // list members land on D, the depth of their cell
     nbody_octree_node o;
     o.center_of_mass[0] = nd.cx; o.center_of_mass[1] = nd.cy; o.center_of_mass[2] = nd.cz; o._pad0 = 0.0f;
     o.pos_min[0] = lo.x; o.pos_min[1] = lo.y; o.pos_min[2] = lo.z; o._pad1 = 0.0f;
     o.pos_max[0] = hi.x; o.pos_max[1] = hi.y; o.pos_max[2] = hi.z;
-    o.range = range[id];
+    o.range = leaf ? 0.0f : range[id];
     o.total_mass = nd.mass;
     for (int k = 0; k < 8; ++k) o.child_indices[k] = 0;
     const uint32_t type = qn_type(nd), cnt = qn_count(nd);
@@ -874,10 +890,11 @@ int nb_tree_create(nbody_ctx* ctx) {
     NB_HIP(ctx, hipMalloc(&T->body_node, n * sizeof(uint32_t)));
     NB_HIP(ctx, hipMalloc(&T->rs_counts, (size_t)256 * T->rs_nb * sizeof(uint32_t)));
     NB_HIP(ctx, hipMalloc(&T->row_total, 256 * sizeof(uint32_t)));
-    NB_HIP(ctx, hipMalloc(&T->row_base, 257 * sizeof(uint32_t)));
     NB_HIP(ctx, hipMalloc(&T->blk, (size_t)NCNT * T->pf_nb * sizeof(uint32_t)));
     NB_HIP(ctx, hipMalloc(&T->lvl_total, NCNT * sizeof(uint32_t)));
     NB_HIP(ctx, hipMalloc(&T->lvl_start, (NCNT + 1) * sizeof(uint32_t)));
+    NB_HIP(ctx, hipHostMalloc(&T->h_lvl_start, (NCNT + 1) * sizeof(uint32_t), hipHostMallocDefault));
+    NB_HIP(ctx, hipEventCreateWithFlags(&T->lvl_ready, hipEventDisableTiming));
     NB_HIP(ctx, hipMalloc(&T->walk_counters, 8 * sizeof(uint64_t)));
     NB_HIP(ctx, hipMalloc(&T->err_flag, sizeof(uint32_t)));
     NB_HIP(ctx, hipMemsetAsync(T->err_flag, 0, sizeof(uint32_t), ctx->stream));
@@ -895,11 +912,13 @@ void nb_tree_destroy(nbody_ctx* ctx) {
         if (T->keys[s]) hipFree(T->keys[s]);
         if (T->idx[s]) hipFree(T->idx[s]);
     }
-    void* ptrs[] = {T->lo, T->top, T->flags, T->body_node, T->rs_counts, T->row_total, T->row_base, T->blk,
+    void* ptrs[] = {T->lo, T->top, T->flags, T->body_node, T->rs_counts, T->row_total, T->blk,
                     T->lvl_total, T->lvl_start, T->nodes, T->node_head, T->bmin, T->bmax, T->range, T->export_buf, T->shard_order, T->shard_blk,
                     T->walk_counters, T->err_flag};
     for (void* p : ptrs)
         if (p) hipFree(p);
+    if (T->h_lvl_start) hipHostFree(T->h_lvl_start);
+    if (T->lvl_ready) hipEventDestroy(T->lvl_ready);
     delete T;
     ctx->tree = nullptr;
 }
@@ -918,9 +937,8 @@ int nb_tree_build(nbody_ctx* ctx, const float4* posm_in) {
     for (int shift = 0; shift < bits; shift += 8) {
         hipLaunchKernelGGL(k_rs_hist, dim3(T->rs_nb), dim3(RS_THREADS), 0, st, T->keys[cur], n, shift, T->rs_counts, T->rs_nb);
         hipLaunchKernelGGL(k_rowscan, dim3(256), dim3(256), 0, st, T->rs_counts, T->rs_nb, T->row_total);
-        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(256), 0, st, T->row_total, T->row_base, 256);
         hipLaunchKernelGGL(k_rs_scatter, dim3(T->rs_nb), dim3(RS_THREADS), 0, st, T->keys[cur], T->idx[cur], T->keys[cur ^ 1],
-                           T->idx[cur ^ 1], n, shift, T->rs_counts, T->row_base, T->rs_nb);
+                           T->idx[cur ^ 1], n, shift, T->rs_counts, T->row_total, T->rs_nb);
         NB_HIP(ctx, hipGetLastError());
         cur ^= 1;
     }
@@ -930,16 +948,29 @@ int nb_tree_build(nbody_ctx* ctx, const float4* posm_in) {
     hipLaunchKernelGGL(k_rowscan, dim3(NCNT), dim3(256), 0, st, T->blk, T->pf_nb, T->lvl_total);
     hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(256), 0, st, T->lvl_total, T->lvl_start, NCNT);
     NB_HIP(ctx, hipGetLastError());
-    NB_HIP(ctx, hipMemcpyAsync(T->h_lvl_start, T->lvl_start, sizeof T->h_lvl_start, hipMemcpyDeviceToHost, st));
-    NB_HIP(ctx, hipStreamSynchronize(st));
-    const uint64_t total = T->h_lvl_start[NCNT];
-    int r = ensure_nodes(ctx, T, total);
-    if (r) return r;
-    T->n_nodes = total;
-    hipLaunchKernelGGL(k_emit, dim3(T->pf_nb), dim3(256), 0, st, T->keys[cur], T->idx[cur], posm_in, n, D, T->lo, T->top,
-                       T->flags, T->blk, T->pf_nb, T->lvl_start, T->nodes, T->bmin, T->bmax, T->range, T->node_head, T->body_node,
-                       (uint32_t)T->cap_nodes, T->err_flag);
+    // The host needs the level sizes for the launches below.  The node emission does not: it is
+    // enqueued behind the copy and runs while the host waits for the copy alone (emission into
+    // the present capacity drops what does not fit; only then is it repeated after growing).
+    NB_HIP(ctx, hipMemcpyAsync(T->h_lvl_start, T->lvl_start, (NCNT + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    NB_HIP(ctx, hipEventRecord(T->lvl_ready, st));
+    auto emit = [&]() {
+        hipLaunchKernelGGL(k_emit, dim3(T->pf_nb), dim3(256), 0, st, T->keys[cur], T->idx[cur], posm_in, n, D, T->lo, T->top,
+                           T->flags, T->blk, T->pf_nb, T->lvl_start, T->nodes, T->bmin, T->bmax, T->range, T->node_head,
+                           T->body_node, (uint32_t)T->cap_nodes, T->err_flag);
+    };
+    emit();
     NB_HIP(ctx, hipGetLastError());
+    NB_HIP(ctx, hipEventSynchronize(T->lvl_ready));
+    const uint64_t total = T->h_lvl_start[NCNT];
+    if (total > T->cap_nodes) {
+        NB_HIP(ctx, hipStreamSynchronize(st));
+        NB_HIP(ctx, hipMemsetAsync(T->err_flag, 0, sizeof(uint32_t), st));  // raised by the emission that did not fit
+        int r = ensure_nodes(ctx, T, total);
+        if (r) return r;
+        emit();
+        NB_HIP(ctx, hipGetLastError());
+    }
+    T->n_nodes = total;
     if (T->h_lvl_start[LIST_ROW + 1] > T->h_lvl_start[LIST_ROW] || T->h_lvl_start[D + 1] > T->h_lvl_start[D]) {
         hipLaunchKernelGGL(k_leaflist, dim3((n + 255) / 256), dim3(256), 0, st, T->keys[cur], T->idx[cur], posm_in, n,
                            ctx->cfg.leaflist_mode, T->flags, T->body_node, T->nodes, T->bmin, T->bmax, T->range, T->node_head,

@@ -182,12 +182,14 @@ def main():
         be.sim.set_counting(False)
         be.sim.set_kernel_timing(True)
         be.sim.kernel_time(bh=True)
+        be.sim.kernel_time(build=True)
         barrier()
         t0 = time.perf_counter()
         sim.step_bh(bsteps)
         barrier()
         bdt = time.perf_counter() - t0
         wms, _ = be.sim.kernel_time(bh=True)
+        bms, _ = be.sim.kernel_time(build=True)
         same = True
         if world > 1:   # replicated state: every rank must have computed the same positions
             with torch.cuda.stream(be.torch_stream):
@@ -200,16 +202,24 @@ def main():
         be.sim.close()
         tot = torch.tensor([c["bh_leaf_interactions"] + c["bh_aggregate_interactions"], c["bh_node_visits"],
                             c["bh_wave_node_visits"]], device="cuda", dtype=torch.float64)
-        mx = torch.tensor([bdt, wms], device="cuda", dtype=torch.float64)
+        mx = torch.tensor([bdt, wms, bms], device="cuda", dtype=torch.float64)
         if world > 1:
             dist.all_reduce(tot, op=dist.ReduceOp.SUM)
             dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         inter, visits, wave_visits = (float(x) for x in tot)
-        bdt, wms = float(mx[0]), float(mx[1])
+        bdt, wms, bms = float(mx[0]), float(mx[1]), float(mx[2])
         # bytes the traversal asks for: 32 B per wavefront node visit + per-body reads/writes
         walk_bytes = (32.0 * wave_visits + nbodies * (16 + 16 + 16)) / world
+        # algorithmic bytes of one (replicated) build: bodies read, keys + indices written, six
+        # sort passes of 12 B in and out, bodies read again for the nodes, 32 B records written and
+        # read once more by the aggregate passes
+        build_bytes = nbodies * (16.0 + 12 + 144 + 16) + c["octree_nodes"] * 64.0
         return {"n_bodies": nbodies, "n_gpus": world, "ranks_hold_identical_positions": same, "theta": 0.5, "max_depth": 16, "steps": bsteps,
                 "steps_per_s": bsteps / bdt, "ms_per_step": bdt / bsteps * 1e3, "walk_kernel_ms": wms,
+                "build_ms": bms,
+                "build_roofline": {"bound": "hbm", "achieved": build_bytes / (bms * 1e-3) / 1e9 if bms > 0 else None,
+                                   "peak": 8000.0, "unit": "GB/s",
+                                   "frac": build_bytes / (bms * 1e-3) / 1e9 / 8000.0 if bms > 0 else None},
                 "octree_nodes": c["octree_nodes"], "interactions_per_step": inter,
                 "interactions_per_s": inter * bsteps / bdt, "node_visits_per_body": visits / nbodies,
                 "wave_node_visits": wave_visits,

@@ -209,10 +209,10 @@ int nbody_device_buffer(nbody_ctx* ctx, int which, void** dev_ptr, size_t* bytes
 int nbody_read_buffer(nbody_ctx* ctx, int which, void* host_dst, size_t bytes);
 /* The hipStream_t the context enqueues on. */
 void* nbody_stream(nbody_ctx* ctx);
-/* Average duration in milliseconds of the dominant kernel (all-pairs force kernel, or the
- * Barnes-Hut traversal kernel) over the launches since the last call, measured with HIP events on
- * the context's stream; *launches receives their count.  Blocks. */
-int nbody_kernel_time(nbody_ctx* ctx, int bh, double* avg_ms, uint64_t* launches);
+/* Average duration in milliseconds, over the launches since the last call, of: which = 0 the
+ * all-pairs force kernel, 1 the Barnes-Hut traversal kernel, 2 one whole octree build (all its
+ * kernels).  Measured with HIP events on the context's stream; *launches receives the count.  Blocks. */
+int nbody_kernel_time(nbody_ctx* ctx, int which, double* avg_ms, uint64_t* launches);
 int nbody_set_kernel_timing(nbody_ctx* ctx, int on);
 
 /* Synthetic initial conditions (host code, no GPU).  Counter-based splitmix64 stream: draw k of

@@ -430,7 +430,7 @@ void launch_ap_ipt(nbody_ctx* ctx, const float4* posm, const float4* vel, int ip
 
 void nb_time_begin(nbody_ctx* ctx, int which) {
     if (!ctx->timing) return;
-    auto& v = which ? ctx->ev_bh : ctx->ev_ap;
+    auto& v = ctx->ev[which];
     if (v.size() >= 2048) nb_time_collect(ctx, which);
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return;
@@ -440,11 +440,11 @@ void nb_time_begin(nbody_ctx* ctx, int which) {
 }
 void nb_time_end(nbody_ctx* ctx, int which) {
     if (!ctx->timing) return;
-    auto& v = which ? ctx->ev_bh : ctx->ev_ap;
+    auto& v = ctx->ev[which];
     if (v.size() >= 2) hipEventRecord(v.back(), ctx->stream);
 }
 int nb_time_collect(nbody_ctx* ctx, int which) {
-    auto& v = which ? ctx->ev_bh : ctx->ev_ap;
+    auto& v = ctx->ev[which];
     if (v.empty()) return NBODY_OK;
     NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (size_t k = 0; k + 1 < v.size(); k += 2) {

@@ -199,6 +199,8 @@ void nbody_destroy(nbody_ctx* ctx) {
     if (ctx->acc_body) hipFree(ctx->acc_body);
     if (ctx->masses) hipFree(ctx->masses);
     if (ctx->energy_dev) hipFree(ctx->energy_dev);
+    for (auto& v : ctx->ev)
+        for (hipEvent_t e : v) hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -471,9 +473,9 @@ int nbody_set_kernel_timing(nbody_ctx* ctx, int on) {
     return NBODY_OK;
 }
 
-int nbody_kernel_time(nbody_ctx* ctx, int bh, double* avg_ms, uint64_t* launches) {
+int nbody_kernel_time(nbody_ctx* ctx, int which, double* avg_ms, uint64_t* launches) {
     if (!ctx) return NBODY_ERR_INVALID;
-    int which = bh ? 1 : 0;
+    if (which < 0 || which > 2) return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_kernel_time: which must be 0, 1 or 2");
     int r = set_device(ctx);
     if (r) return r;
     r = nb_time_collect(ctx, which);

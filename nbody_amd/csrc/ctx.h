@@ -51,9 +51,9 @@ struct nbody_ctx {
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;  // pairs
     size_t ev_used[2] = {0, 0};       // [0]=all-pairs, [1]=bh : number of recorded pairs
-    std::vector<hipEvent_t> ev_ap, ev_bh;
-    double time_acc_ms[2] = {0, 0};
-    uint64_t time_launches[2] = {0, 0};
+    std::vector<hipEvent_t> ev[3];  // 0 all-pairs force kernel, 1 traversal kernel, 2 octree build (all its launches)
+    double time_acc_ms[3] = {0, 0, 0};
+    uint64_t time_launches[3] = {0, 0, 0};
 };
 
 extern thread_local std::string g_nbody_create_error;

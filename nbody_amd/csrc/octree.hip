@@ -929,6 +929,7 @@ int nb_tree_build(nbody_ctx* ctx, const float4* posm_in) {
     const uint32_t n = (uint32_t)T->n;
     const int D = (int)T->D;
     hipStream_t st = ctx->stream;
+    nb_time_begin(ctx, 2);
     hipLaunchKernelGGL(k_morton, dim3((n + 255) / 256), dim3(256), 0, st, posm_in, n, ctx->cfg.world, D, T->keys[0],
                        T->idx[0]);
     NB_HIP(ctx, hipGetLastError());
@@ -984,6 +985,7 @@ int nb_tree_build(nbody_ctx* ctx, const float4* posm_in) {
         hipLaunchKernelGGL(k_aggregate, dim3((count + 255) / 256), dim3(256), 0, st, T->nodes, T->bmin, T->bmax, T->range, first,
                            count, T->h_lvl_start[d + 2], mac);
     }
+    nb_time_end(ctx, 2);
     NB_HIP(ctx, hipGetLastError());
     T->have_tree = true;
     T->built = true;

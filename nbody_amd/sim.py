@@ -209,9 +209,11 @@ class NBodySim:
     def set_kernel_timing(self, on):
         self._ck(self.lib.nbody_set_kernel_timing(self.h, int(on)))
 
-    def kernel_time(self, bh=False):
+    def kernel_time(self, bh=False, build=False):
+        """(average ms, launches) since the last call: the all-pairs force kernel, with bh the
+        traversal kernel, with build one whole octree build."""
         ms, cnt = C.c_double(), C.c_uint64()
-        self._ck(self.lib.nbody_kernel_time(self.h, int(bh), C.byref(ms), C.byref(cnt)))
+        self._ck(self.lib.nbody_kernel_time(self.h, 2 if build else int(bool(bh)), C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
 
     def device_buffer(self, which):

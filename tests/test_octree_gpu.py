@@ -312,3 +312,38 @@ def test_upload_rejects_bad_tree(orc):
             sim.upload_octree(bad)
         with pytest.raises(nb.NBodyError):
             sim.accel_bh()          # no tree yet
+
+
+def test_ranked_forces_and_integration_equal_a_plain_step(orc):
+    """The replicated-state multi-GPU scheme on one context: traversal by runs of the sorted order
+    into the rank-ordered buffer, then un-ranking + integration of all bodies == nbody_step_bh."""
+    import nbody_amd as nb
+    n = 5003
+    m, pos, vel = nb.gen_plummer(n, seed=9, equilibrium=True)
+    with nb.NBodySim(n, law=1) as ref:
+        ref.upload(m, pos, vel)
+        ref.step_bh(2)
+        rp, rv, ra = ref.download()
+        _, _, order = ref.morton_keys()     # of the octree the second step built
+    with nb.NBodySim(n, law=1) as sim:
+        sim.upload(m, pos, vel)
+        for step in range(2):
+            for b, c in ((0, 1700), (1700, 3303), (5003, 0)):     # uneven runs, an empty one
+                sim.bh_forces_ranked(b, c)
+            if step == 1:
+                ranked = sim.read_buffer(nb.BUF_ACC_PARTIAL)
+            sim.integrate_ranked()
+        p, v, a = sim.download()
+    assert np.array_equal(p, rp) and np.array_equal(v, rv) and np.array_equal(a, ra)
+    # the exchanged buffer holds, at rank r, the acceleration of the r-th body of the sorted order
+    assert np.array_equal(ranked[:, :3], a[order][:, :3])
+    with nb.NBodySim(n, law=1, shard_begin=0, shard_count=n // 2) as sharded:
+        sharded.upload(m, pos, vel)
+        with pytest.raises(nb.NBodyError):
+            sharded.bh_forces_ranked(0, 10)       # needs a context that holds all bodies
+    with nb.NBodySim(n, law=1) as sim:
+        sim.upload(m, pos, vel)
+        with pytest.raises(nb.NBodyError):
+            sim.bh_forces_ranked(n - 5, 10)       # run outside the bodies
+        with pytest.raises(nb.NBodyError):
+            sim.integrate_ranked()                # no octree built yet

@@ -42,7 +42,8 @@ constexpr uint32_t NO_NODE = 0xffffffffu;
 // The acceptance test range / distance < theta (src/nbodybh.wgsl:104-106) is prepared per node
 // as two thresholds on the squared distance: r^2 > r2_accept settles "accept", r^2 < r2_open
 // settles "open"; in the narrow band between them (relative width 8e-6) the traversal evaluates
-// the reference's expression itself, with the node's range from a side array.
+// the reference's expression itself, with the node's range from a side array.  A LEAFBODY record
+// has both thresholds below zero (QN_ALWAYS).
 struct QNode {
     float cx, cy, cz, mass;
     float r2_open, r2_accept;
@@ -52,6 +53,10 @@ struct QNode {
 __host__ __device__ __forceinline__ uint32_t qn_type(const QNode& nd) { return nd.count_type >> 30; }
 __host__ __device__ __forceinline__ uint32_t qn_count(const QNode& nd) { return nd.count_type & 0x3fffffffu; }
 __host__ __device__ __forceinline__ uint32_t qn_pack(uint32_t count, uint32_t type) { return (type << 30) | count; }
+
+// Thresholds of a LEAFBODY record: any squared distance exceeds them, so the traversal takes the
+// record as a source for every lane without looking at its type.
+constexpr float QN_ALWAYS = -1.0f;
 
 // 1 / (theta^2 (1 +- 4e-6)): the squared-distance thresholds of a node are range^2 times these.
 struct MacScale {
@@ -441,7 +446,7 @@ __global__ __launch_bounds__(256) void k_emit(const uint64_t* __restrict__ keys,
                 else type = NBODY_NODE_LEAFBODY;
                 QNode nd;
                 nd.cx = p.x; nd.cy = p.y; nd.cz = p.z; nd.mass = p.w;  // src/octree_maxdepth.rs:75-86 for a LEAFBODY;
-                nd.r2_open = nd.r2_accept = 0.0f;                      // aggregates are filled in later otherwise
+                nd.r2_open = nd.r2_accept = QN_ALWAYS;                 // aggregates are filled in later otherwise
                 nd.first = 0;
                 nd.count_type = qn_pack(0, type);
                 nodes[id] = nd;
@@ -478,7 +483,7 @@ __global__ void k_leaflist(const uint64_t* __restrict__ keys, const uint32_t* __
         if (member < cap_nodes) {
             QNode c;
             c.cx = q.x; c.cy = q.y; c.cz = q.z; c.mass = q.w;
-            c.r2_open = c.r2_accept = 0.0f;
+            c.r2_open = c.r2_accept = QN_ALWAYS;
             c.first = 0;
             c.count_type = qn_pack(0, NBODY_NODE_LEAFBODY);
             nodes[member] = c;
@@ -595,6 +600,7 @@ __global__ void k_import(const nbody_octree_node* __restrict__ in, uint32_t coun
     nd.cx = o.center_of_mass[0]; nd.cy = o.center_of_mass[1]; nd.cz = o.center_of_mass[2];
     nd.mass = o.total_mass;
     qn_set_range(nd, o.range, mac);
+    if (o.node_type == NBODY_NODE_LEAFBODY) nd.r2_open = nd.r2_accept = QN_ALWAYS;
     nd.first = 0;
     uint32_t cnt = 0;
     if (o.node_type == NBODY_NODE_INTERIOR) {
@@ -679,6 +685,7 @@ __global__ __launch_bounds__(256) void k_compact_scatter(const uint32_t* __restr
 // children are fetched together when it is popped.
 constexpr bool WALK_PRECISE = false;  // one Newton step on v_rsq_f32 in the traversal's interactions
 constexpr int WALK_STACK = 160;  // >= 8 pushes per level x 17 levels + root
+constexpr int WALK_THREADS = 256;  // (one wavefront per workgroup was measured 5 % slower)
 constexpr int WALK_BATCH = 8;    // node records fetched together; the node array is padded by as many
 
 // The lanes for which p holds, as a wave-uniform value the compiler keeps in scalar registers
@@ -697,7 +704,7 @@ __device__ __forceinline__ void pin_record(const QNode& nd) {
 }
 
 template <int LAW, bool COUNT>
-__global__ __launch_bounds__(256) void k_walk(const QNode* __restrict__ q, const uint32_t* __restrict__ order, uint32_t m,
+__global__ __launch_bounds__(WALK_THREADS) void k_walk(const QNode* __restrict__ q, const uint32_t* __restrict__ order, uint32_t m,
                                               uint32_t i_begin, const float4* __restrict__ posm,
                                               const float4* __restrict__ vel, float4* __restrict__ acc_out, float G,
                                               float eps2, float theta, const float* __restrict__ range,
@@ -705,9 +712,9 @@ __global__ __launch_bounds__(256) void k_walk(const QNode* __restrict__ q, const
                                               uint32_t* __restrict__ err_flag, int out_by_rank) {
     // Target r of this launch is body order[r] (or i_begin + r without an order); its result goes
     // to acc_out[body], or with out_by_rank to acc_out[i_begin + r].
-    __shared__ uint4 st[4][WALK_STACK];  // {first, count, mask.lo, mask.hi}
+    __shared__ uint4 st[WALK_THREADS / 64][WALK_STACK];  // {first, count, mask.lo, mask.hi}
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t r = blockIdx.x * 256 + tid;
+    const uint32_t r = blockIdx.x * WALK_THREADS + tid;
     const bool valid = r < m;
     const uint32_t b = valid ? (order ? order[r] : i_begin + r) : 0u;
     Tgt t;
@@ -765,30 +772,33 @@ __global__ __launch_bounds__(256) void k_walk(const QNode* __restrict__ q, const
                 }
                 const float dx = nd.cx - t.x, dy = nd.cy - t.y, dz = nd.cz - t.z;
                 const float r2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
-                // lanes that take this node as one source; LEAFBODY: all of the group's
-                // (a direct interaction, src/nbodybh.wgsl:76-102)
-                unsigned long long take = mask;
-                if (qn_type(nd) != NBODY_NODE_LEAFBODY) {
-                    // src/nbodybh.wgsl:104-106 by the node's squared-distance thresholds; the
-                    // reference's own expression decides inside the band between them
-                    const unsigned long long far = lanes(r2 > nd.r2_accept), near = lanes(r2 < nd.r2_open);
-                    take = mask & far;
-                    const unsigned long long unsure = mask & ~(far | near);
+                // Lanes that take this node as one source.  src/nbodybh.wgsl:104-106 by the node's
+                // squared-distance thresholds; a LEAFBODY record (a direct interaction,
+                // src/nbodybh.wgsl:76-102) carries thresholds below zero, which every lane passes.
+                unsigned long long take = mask & lanes(r2 > nd.r2_accept);
+                const unsigned long long rest = mask & ~take;
+                if (rest) {
+                    // not clearly accepted: clearly to be opened, or inside the band between the
+                    // thresholds, where the reference's own expression decides
+                    unsigned long long open = rest;
+                    const unsigned long long unsure = rest & ~lanes(r2 < nd.r2_open);
                     if (unsure) {
                         const float rg = range[first + b0 + k];
                         const float rr = sqrtf(((dx * dx) + (dy * dy)) + (dz * dz));  // distance(pos, com)
-                        take |= unsure & lanes((rg / rr) < theta);
+                        const unsigned long long yes = unsure & lanes((rg / rr) < theta);
+                        take |= yes;
+                        open &= ~yes;
                     }
-                    const unsigned long long open = mask & ~take;
                     if (open) {
                         // INTERIOR: its children; LEAFLIST: its members (LEAFBODY records, src/nbodybh.wgsl:137-146)
                         stack[top] = make_uint4(nd.first, qn_count(nd), (uint32_t)open, (uint32_t)(open >> 32));
                         ++top;
                         if (COUNT) max_top = max(max_top, (uint32_t)top);
                     }
-                    if (COUNT) n_agg += __builtin_amdgcn_inverse_ballot_w64(take);
-                } else if (COUNT) {
-                    n_leaf += __builtin_amdgcn_inverse_ballot_w64(take);
+                }
+                if (COUNT) {
+                    if (qn_type(nd) == NBODY_NODE_LEAFBODY) n_leaf += __builtin_amdgcn_inverse_ballot_w64(take);
+                    else n_agg += __builtin_amdgcn_inverse_ballot_w64(take);
                 }
                 if (take) {
                     // every lane evaluates the term; lanes that do not take it add zero
@@ -859,13 +869,13 @@ int check_err_flag(nbody_ctx* ctx, Octree* T, const char* what) {
 template <int LAW>
 void launch_walk(nbody_ctx* ctx, Octree* T, const uint32_t* order, uint32_t m, const float4* posm, const float4* vel,
                  float4* acc_out, uint32_t i_begin, int out_by_rank) {
-    dim3 grid((m + 255) / 256);
+    dim3 grid((m + WALK_THREADS - 1) / WALK_THREADS);
     if (ctx->counting)
-        hipLaunchKernelGGL((k_walk<LAW, true>), grid, dim3(256), 0, ctx->stream, T->nodes, order, m, i_begin,
+        hipLaunchKernelGGL((k_walk<LAW, true>), grid, dim3(WALK_THREADS), 0, ctx->stream, T->nodes, order, m, i_begin,
                            posm, vel, acc_out, ctx->cfg.G, ctx->cfg.eps2, ctx->cfg.theta, T->range,
                            (unsigned long long*)T->walk_counters, T->err_flag, out_by_rank);
     else
-        hipLaunchKernelGGL((k_walk<LAW, false>), grid, dim3(256), 0, ctx->stream, T->nodes, order, m, i_begin,
+        hipLaunchKernelGGL((k_walk<LAW, false>), grid, dim3(WALK_THREADS), 0, ctx->stream, T->nodes, order, m, i_begin,
                            posm, vel, acc_out, ctx->cfg.G, ctx->cfg.eps2, ctx->cfg.theta, T->range,
                            (unsigned long long*)T->walk_counters, T->err_flag, out_by_rank);
 }

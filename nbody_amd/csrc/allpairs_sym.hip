@@ -20,6 +20,7 @@
 // kernel.
 #include "ctx.h"
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -179,7 +180,8 @@ __global__ __launch_bounds__(256) void k_ap_sym(const float4* __restrict__ posm,
 template <bool SINGLE>  // SINGLE: nparts == 1, every row counts and the loads are issued in batches
 __global__ void k_ap_sym_reduce(const float4* __restrict__ diag, const float4* __restrict__ part_j,
                                 const float4* __restrict__ part_i, const unsigned long long* __restrict__ rowoff,
-                                const uint32_t* __restrict__ item_start, int n, int SB, uint32_t seg, float G,
+                                const uint32_t* __restrict__ item_start, int n, int SB,
+                                const uint32_t* __restrict__ seg_of, float G,
                                 float pair_scale, uint32_t part, uint32_t nparts, int own_begin, int own_end,
                                 int diag_slices, float4* __restrict__ acc_out) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -203,7 +205,7 @@ __global__ void k_ap_sym_reduce(const float4* __restrict__ diag, const float4* _
     }
     for (; a < b; ++a) {
         // the work item that covered (a, j's tile); with nparts > 1 only this part's items count
-        const uint32_t item = item_start[a] + (uint32_t)((j - (a + 1) * SB) / TILE) / seg;
+        const uint32_t item = item_start[a] + (uint32_t)((j - (a + 1) * SB) / TILE) / seg_of[a];
         if (!SINGLE && sym_owner(item, nparts) != part) continue;
         const float4 p = part_j[rowoff[a] + (unsigned long long)(j - (a + 1) * SB)];
         x += p.x;
@@ -253,7 +255,8 @@ __global__ void k_ap_sym_reduce(const float4* __restrict__ diag, const float4* _
 struct SymPlan {
     uint64_t n = 0;
     uint32_t sb = 0;   // bodies per superblock
-    uint32_t seg = 0;  // source tiles per work item
+    uint32_t seg = 0;  // source tiles per work item of the first superblocks (later ones: fewer, see sym_seg_of)
+    uint32_t* seg_of = nullptr;  // [superblocks] source tiles per work item
     uint32_t n_items = 0;
     SymItem* items = nullptr;
     unsigned long long* rowoff = nullptr;
@@ -266,22 +269,43 @@ struct SymPlan {
 void nb_sym_destroy(nbody_ctx* ctx) {
     SymPlan* P = ctx->sym;
     if (!P) return;
-    void* ptrs[] = {P->items, P->rowoff, P->item_start, P->part_j, P->part_i, P->diag};
+    void* ptrs[] = {P->items, P->rowoff, P->item_start, P->seg_of, P->part_j, P->part_i, P->diag};
     for (void* p : ptrs)
         if (p) hipFree(p);
     delete P;
     ctx->sym = nullptr;
 }
 
+// Source tiles per work item for every superblock.  Work items are dispatched in superblock
+// order and the GPU holds only ~1000 of them at a time, so the last ones decide how long the
+// kernel's tail is: superblocks that start after 70 / 85 / 95 % of all the pair work get items of
+// 1/2, 1/4, 1/8 the size.
+static std::vector<uint32_t> sym_seg_of(uint64_t n, uint32_t seg_tiles, uint32_t SB) {
+    const uint64_t nsb = (n + SB - 1) / SB, nt = (n + TILE - 1) / TILE, TPS = SB / TILE;
+    std::vector<uint32_t> seg(nsb, seg_tiles);
+    uint64_t total = 0;
+    for (uint64_t a = 0; a < nsb; ++a) total += nt > (a + 1) * TPS ? nt - (a + 1) * TPS : 0;
+    uint64_t done = 0;
+    for (uint64_t a = 0; a < nsb; ++a) {
+        const double frac = total ? (double)done / (double)total : 0.0;
+        static const bool taper = !getenv("NBODY_AP_NO_TAPER");  // (for measurements)
+        const uint32_t div = !taper ? 1u : frac < 0.70 ? 1u : frac < 0.85 ? 2u : frac < 0.95 ? 4u : 8u;
+        seg[a] = std::max(4u, seg_tiles / div);
+        done += nt > (a + 1) * TPS ? nt - (a + 1) * TPS : 0;
+    }
+    return seg;
+}
+
 // Bytes of scratch the symmetric path needs for n bodies (0 if it does not apply).
 uint64_t nb_sym_scratch_bytes(uint64_t n, uint32_t seg_tiles, uint32_t SB) {
     const uint64_t nsb = (n + SB - 1) / SB, nt = (n + TILE - 1) / TILE, TILES_PER_SB = SB / TILE;
     if (nsb < 2) return 0;
+    const std::vector<uint32_t> seg = sym_seg_of(n, seg_tiles, SB);
     uint64_t rows = 0, items = 0;
     for (uint64_t a = 0; a + 1 < nsb; ++a) {
         const uint64_t tiles = nt - (a + 1) * TILES_PER_SB;
         rows += tiles * TILE;
-        items += (tiles + seg_tiles - 1) / seg_tiles;
+        items += (tiles + seg[a] - 1) / seg[a];
     }
     return (rows + items * SB + (SB / NB_DIAG_TILE) * n) * sizeof(float4);
 }
@@ -298,6 +322,7 @@ static int sym_prepare(nbody_ctx* ctx, uint32_t seg_tiles, uint32_t SB) {
     const uint64_t n = ctx->n;
     const uint32_t nsb = (uint32_t)((n + SB - 1) / SB), nt = (uint32_t)((n + TILE - 1) / TILE);
     std::vector<SymItem> items;
+    const std::vector<uint32_t> seg_of = sym_seg_of(n, seg_tiles, SB);
     std::vector<unsigned long long> rowoff(nsb + 1, 0);
     std::vector<uint32_t> item_start(nsb + 1, 0);
     unsigned long long rows = 0;
@@ -306,7 +331,7 @@ static int sym_prepare(nbody_ctx* ctx, uint32_t seg_tiles, uint32_t SB) {
         item_start[a] = (uint32_t)items.size();
         const uint32_t first = (a + 1) * TILES_PER_SB;
         if (first < nt) {
-            for (uint32_t t = first; t < nt; t += seg_tiles) items.push_back(SymItem{a, t, std::min(nt, t + seg_tiles), 0});
+            for (uint32_t t = first; t < nt; t += seg_of[a]) items.push_back(SymItem{a, t, std::min(nt, t + seg_of[a]), 0});
             rows += (unsigned long long)(nt - first) * TILE;
         }
     }
@@ -316,6 +341,8 @@ static int sym_prepare(nbody_ctx* ctx, uint32_t seg_tiles, uint32_t SB) {
     NB_HIP(ctx, hipMalloc(&P->items, std::max<size_t>(1, items.size()) * sizeof(SymItem)));
     NB_HIP(ctx, hipMalloc(&P->rowoff, rowoff.size() * sizeof(unsigned long long)));
     NB_HIP(ctx, hipMalloc(&P->item_start, item_start.size() * sizeof(uint32_t)));
+    NB_HIP(ctx, hipMalloc(&P->seg_of, seg_of.size() * sizeof(uint32_t)));
+    NB_HIP(ctx, hipMemcpyAsync(P->seg_of, seg_of.data(), seg_of.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     NB_HIP(ctx, hipMalloc(&P->part_j, std::max<unsigned long long>(1, rows) * sizeof(float4)));
     NB_HIP(ctx, hipMalloc(&P->part_i, std::max<size_t>(1, items.size()) * SB * sizeof(float4)));
     NB_HIP(ctx, hipMalloc(&P->diag, (size_t)(SB / NB_DIAG_TILE) * n * sizeof(float4)));
@@ -355,11 +382,11 @@ int nb_allpairs_forces_sym(nbody_ctx* ctx, const float4* posm_in, float4* acc_ou
     if (r) return r;
     if (nparts == 1)
         hipLaunchKernelGGL(k_ap_sym_reduce<true>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, P->diag, P->part_j, P->part_i,
-                           P->rowoff, P->item_start, n, (int)SB, P->seg, ctx->cfg.G, uniform ? ctx->mass0 : 1.0f, part, nparts,
+                           P->rowoff, P->item_start, n, (int)SB, P->seg_of, ctx->cfg.G, uniform ? ctx->mass0 : 1.0f, part, nparts,
                            (int)ctx->i_begin, (int)(ctx->i_begin + ctx->i_count), (int)(SB / NB_DIAG_TILE), acc_out);
     else
         hipLaunchKernelGGL(k_ap_sym_reduce<false>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, P->diag, P->part_j, P->part_i,
-                           P->rowoff, P->item_start, n, (int)SB, P->seg, ctx->cfg.G, uniform ? ctx->mass0 : 1.0f, part, nparts,
+                           P->rowoff, P->item_start, n, (int)SB, P->seg_of, ctx->cfg.G, uniform ? ctx->mass0 : 1.0f, part, nparts,
                            (int)ctx->i_begin, (int)(ctx->i_begin + ctx->i_count), (int)(SB / NB_DIAG_TILE), acc_out);
     NB_HIP(ctx, hipGetLastError());
     ctx->counters.interactions_allpairs += ctx->n * ctx->n / nparts;

@@ -6,7 +6,7 @@ import nbody_amd as nb
 from nbody_amd.shard import shard_range
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
 m, p, v = nb.gen_plummer(n, seed=42)
-for world in (1, 2, 4, 8):
+for world in [int(w) for w in os.environ.get("WORLDS", "1,2,4,8").split(",")]:
     for rank in sorted({0, world // 2, world - 1}, reverse=True):
         b, c = shard_range(n, rank, world)
         with nb.NBodySim(n, law=nb.LAW_PLUMMER, shard_begin=b, shard_count=c) as sim:

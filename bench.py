@@ -112,6 +112,11 @@ def main():
         be.sim.close()
         return dt, kms, launches, agree
 
+    pair = world > 1 and args.law == "plummer" and n >= HipShardBackend.PAIR_SHARD_MIN_N
+    scheme = "single" if world == 1 else (f"pair-shard x{world}" if pair else f"target-shard x{world}")
+    scheme_text = ("" if world == 1 else
+                   ": pair tiles dealt over the ranks, per-step all-reduce of partial accelerations + all-gather of positions"
+                   if pair else ": targets split by index range, per-step all-gather of positions")
     dt, kernel_ms, launches, agree = timed_run(law, args.steps, args.warmup)
     interactions = float(n) * n * args.steps
     flop = FLOP_PER_INTERACTION[args.law]
@@ -134,9 +139,8 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"all-pairs direct sum, N={n} Plummer sphere (a=12.5, equal masses, seed 42), "
-                               f"law={args.law}, velocity-Verlet dt=0.1, {args.gpus} GPU(s): pair tiles dealt over the "
-                               "ranks, per-step all-reduce of partial accelerations + all-gather of positions",
-                   "n_bodies": n, "law": args.law, "parallelism": f"target-shard x{args.gpus}"},
+                               f"law={args.law}, velocity-Verlet dt=0.1, {args.gpus} GPU(s)" + scheme_text,
+                   "n_bodies": n, "law": args.law, "parallelism": scheme},
         "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
                      "kernel": ("k_ap_sym" if (args.law == "plummer" and n >= 65536) else
@@ -166,13 +170,13 @@ def main():
                                 "ms_per_step": wdt / wsteps * 1e3, "achieved_tflops": wach,
                                 "frac": wach / PEAK_FP32_TFLOPS, "steps": wsteps}
 
-    def bh_leg(nbodies, bsteps):
+    def bh_leg(nbodies, bsteps, bh_law=None):
         """Barnes-Hut step, theta = 0.5, depth cap 16.  With several GPUs every rank holds all bodies:
         replicated octree build, traversal of this rank's run of the sorted (Morton) order,
         all-gather of the accelerations (16 B/body), integration + clamp of all bodies."""
         m_, p_, v_ = (masses, pos, vel) if nbodies == n else nb.gen_plummer(nbodies, seed=42)
         b_, c_ = shard_range(nbodies, rank, world)
-        be = HipShardBackend(nbodies, b_, c_, local_rank, law=nb.LAW_PLUMMER, bh_ranked=True)
+        be = HipShardBackend(nbodies, b_, c_, local_rank, law=nb.LAW_PLUMMER if bh_law is None else bh_law, bh_ranked=True)
         be.upload(m_, p_, v_)
         sim = ShardedSim(be, nbodies, rank, world)
         sim.step_bh(2)
@@ -214,7 +218,8 @@ def main():
         # sort passes of 12 B in and out, bodies read again for the nodes, 32 B records written and
         # read once more by the aggregate passes
         build_bytes = nbodies * (16.0 + 12 + 144 + 16) + c["octree_nodes"] * 64.0
-        return {"n_bodies": nbodies, "n_gpus": world, "ranks_hold_identical_positions": same, "theta": 0.5, "max_depth": 16, "steps": bsteps,
+        return {"n_bodies": nbodies, "n_gpus": world, "law": "plummer" if bh_law in (None, nb.LAW_PLUMMER) else "wgsl_bias",
+                "ranks_hold_identical_positions": same, "theta": 0.5, "max_depth": 16, "steps": bsteps,
                 "steps_per_s": bsteps / bdt, "ms_per_step": bdt / bsteps * 1e3, "walk_kernel_ms": wms,
                 "build_ms": bms,
                 "build_roofline": {"bound": "hbm", "achieved": build_bytes / (bms * 1e-3) / 1e9 if bms > 0 else None,
@@ -228,6 +233,8 @@ def main():
 
     if not args.no_extras and args.law == "plummer":
         out["barnes_hut"] = bh_leg(n, 20)
+        # the reference's traversal shader applies its acos/pow bias too (src/nbodybh.wgsl:90-101)
+        out["barnes_hut_wgsl_bias_law"] = bh_leg(n, 10, nb.LAW_WGSL_BIAS)
         if n == 1 << 20:
             out["barnes_hut_16m"] = bh_leg(1 << 24, 5)
     if rank == 0 and args.gpus == 1 and not args.no_extras:

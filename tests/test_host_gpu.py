@@ -43,3 +43,26 @@ def test_headless_host_matches_oracle(orc, mode):
     else:
         p, _, _ = orc.step_bh(orc.LAW_WGSL_BIAS, m, pos, z, z, frames)
     assert np.allclose(got, p[0, :3], rtol=0, atol=2e-4), (got, p[0, :3])
+
+
+def test_headless_host_dumps_renderer_frames(tmp_path):
+    """--dump writes masses and per-frame positions in the layout the reference's renderer binds
+    (src/trace.wgsl:23-27: f32 masses, vec3 positions at a 16-byte stride)."""
+    import nbody_amd as nb
+    n, frames, every = 300, 6, 2
+    path = tmp_path / "frames.bin"
+    r = subprocess.run([EXE, "--mode", "gpu", "--n", str(n), "--frames", str(frames), "--report", str(every),
+                        "--seed", "7", "--dump", str(path)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    raw = path.read_bytes()
+    head = np.frombuffer(raw[:16], np.uint32)
+    assert raw[:4] == b"NBF1" and head[1] == n and head[2] == frames // every
+    assert len(raw) == 16 + 4 * n + (frames // every) * 16 * n
+    m, pos = nb.gen_refcube(n, seed=7)
+    assert np.array_equal(np.frombuffer(raw[16:16 + 4 * n], np.float32), m)
+    with nb.NBodySim(n, law=nb.LAW_WGSL_BIAS) as sim:
+        sim.upload(m, pos)
+        sim.step_allpairs(frames)
+        p, _, _ = sim.download()
+    last = np.frombuffer(raw[-16 * n:], np.float32).reshape(n, 4)
+    assert np.array_equal(last, p)

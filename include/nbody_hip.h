@@ -50,8 +50,14 @@ enum nbody_law {
 enum nbody_integrator {
     /* src/nbody_cpu.rs:345-348,358-360: acc2=a; vel2+=a; pos2+=vel2; swap sets (two interleaved states). */
     NBODY_INT_CPU_EULER_XBUF = 0,
-    /* src/nbody.wgsl:132-138: pos+=vel*dt+0.5*acc_in*dt^2; vel+=0.5*(acc_in+acc)*dt. */
-    NBODY_INT_WGSL_VERLET = 1
+    /* src/nbody.wgsl:132-138: pos+=vel*dt+0.5*acc_in*dt^2; vel+=0.5*(acc_in+acc)*dt.  (The position
+     * update uses the PREVIOUS step's acceleration: first order in the energy, about 6 % drift over
+     * 1,000 steps of a Plummer sphere.) */
+    NBODY_INT_WGSL_VERLET = 1,
+    /* Opt-in, no counterpart in the reference: kick-drift leapfrog, vel+=acc*dt (dt/2 on the first
+     * step after an upload); pos+=vel*dt.  Time-centred and symplectic; the stored velocity is the
+     * half-step one. */
+    NBODY_INT_LEAPFROG = 2
 };
 
 /* Node types of src/octree_maxdepth.rs:8-11. */

@@ -329,6 +329,31 @@ __global__ void k_integrate_verlet(const float4* __restrict__ posm_in, const flo
     acc_out[i] = make_float4(a1.x, a1.y, a1.z, 0.0f);
 }
 
+// Kick-drift leapfrog (no counterpart in the reference): v += a dt_kick; x += v dt.
+__global__ void k_integrate_leapfrog(const float4* __restrict__ posm_in, const float4* __restrict__ vel_in,
+                                     const float4* __restrict__ acc_new, float4* __restrict__ posm_out,
+                                     float4* __restrict__ vel_out, float4* __restrict__ acc_out, int i_begin, int i_count,
+                                     float dt, float dt_kick, float clamp_world) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= i_count) return;
+    int i = i_begin + r;
+    const float4 p = posm_in[i], v = vel_in[i], a = acc_new[i];
+    const float vx = __fadd_rn(v.x, __fmul_rn(a.x, dt_kick));
+    const float vy = __fadd_rn(v.y, __fmul_rn(a.y, dt_kick));
+    const float vz = __fadd_rn(v.z, __fmul_rn(a.z, dt_kick));
+    float px = __fadd_rn(p.x, __fmul_rn(vx, dt));
+    float py = __fadd_rn(p.y, __fmul_rn(vy, dt));
+    float pz = __fadd_rn(p.z, __fmul_rn(vz, dt));
+    if (clamp_world > 0.0f) {
+        px = fminf(fmaxf(px, 0.0f), clamp_world);
+        py = fminf(fmaxf(py, 0.0f), clamp_world);
+        pz = fminf(fmaxf(pz, 0.0f), clamp_world);
+    }
+    posm_out[i] = make_float4(px, py, pz, p.w);
+    vel_out[i] = make_float4(vx, vy, vz, 0.0f);
+    acc_out[i] = make_float4(a.x, a.y, a.z, 0.0f);
+}
+
 // src/nbody_cpu.rs:345-348: the OTHER buffer set is advanced in place.
 __global__ void k_integrate_cpu_xbuf(const float4* __restrict__ acc_new, float4* __restrict__ posm_alt,
                                      float4* __restrict__ vel_alt, float4* __restrict__ acc_alt, int i_begin,
@@ -552,12 +577,25 @@ int nb_allpairs_forces(nbody_ctx* ctx, const float4* posm_in, const float4* vel_
 }
 
 // Advance the state with the accelerations acc_new (indexed by global body) and swap the sets.
+// The first leapfrog step after an upload kicks by dt/2: uploaded velocities are on the step.
+static void launch_leapfrog(nbody_ctx* ctx, const float4* acc_new, float clamp_world) {
+    unsigned fb = (unsigned)((ctx->i_count + 255) / 256);
+    const int c = ctx->cur, o = ctx->cur ^ 1;
+    const float dt = ctx->cfg.dt;
+    hipLaunchKernelGGL(k_integrate_leapfrog, dim3(fb), dim3(256), 0, ctx->stream, ctx->posm[c], ctx->vel[c], acc_new,
+                       ctx->posm[o], ctx->vel[o], ctx->acc[o], (int)ctx->i_begin, (int)ctx->i_count, dt,
+                       ctx->leapfrog_started ? dt : 0.5f * dt, clamp_world);
+    ctx->leapfrog_started = true;
+}
+
 int nb_integrate(nbody_ctx* ctx, const float4* acc_new) {
     unsigned fb = (unsigned)((ctx->i_count + 255) / 256);
     const int c = ctx->cur, o = ctx->cur ^ 1;
     if (ctx->cfg.integrator == NBODY_INT_CPU_EULER_XBUF) {
         hipLaunchKernelGGL(k_integrate_cpu_xbuf, dim3(fb), dim3(256), 0, ctx->stream, acc_new, ctx->posm[o], ctx->vel[o],
                            ctx->acc[o], (int)ctx->i_begin, (int)ctx->i_count);
+    } else if (ctx->cfg.integrator == NBODY_INT_LEAPFROG) {
+        launch_leapfrog(ctx, acc_new, 0.0f);
     } else {
         const float dt = ctx->cfg.dt;
         const float dt2 = std::pow(dt, 2.0f);  // pow(time_step, 2.0), src/nbody.wgsl:132
@@ -573,6 +611,12 @@ int nb_integrate(nbody_ctx* ctx, const float4* acc_new) {
 int nb_integrate_clamped(nbody_ctx* ctx, const float4* acc_new) {
     unsigned fb = (unsigned)((ctx->i_count + 255) / 256);
     const int c = ctx->cur, o = ctx->cur ^ 1;
+    if (ctx->cfg.integrator == NBODY_INT_LEAPFROG) {
+        launch_leapfrog(ctx, acc_new, ctx->cfg.world);
+        NB_HIP(ctx, hipGetLastError());
+        ctx->cur = o;
+        return NBODY_OK;
+    }
     const float dt = ctx->cfg.dt;
     const float dt2 = std::pow(dt, 2.0f);
     hipLaunchKernelGGL(k_integrate_verlet, dim3(fb), dim3(256), 0, ctx->stream, ctx->posm[c], ctx->vel[c], ctx->acc[c],

@@ -111,7 +111,7 @@ int nbody_create(nbody_ctx** out, const nbody_config* cfg) {
         g_nbody_create_error = "nbody_create: n_bodies must be in [1, 2^30]";
         return NBODY_ERR_INVALID;
     }
-    if (cfg->law < 0 || cfg->law > 2 || cfg->integrator < 0 || cfg->integrator > 1) {
+    if (cfg->law < 0 || cfg->law > 2 || cfg->integrator < 0 || cfg->integrator > 2) {
         g_nbody_create_error = "nbody_create: unknown law or integrator";
         return NBODY_ERR_INVALID;
     }
@@ -212,6 +212,7 @@ int nbody_upload(nbody_ctx* ctx, const float* host_masses, const float* host_pos
     int r = set_device(ctx);
     if (r) return r;
     ctx->cur = 0;
+    ctx->leapfrog_started = false;
     ctx->mass0 = host_masses[0];
     ctx->uniform_mass = true;
     for (uint64_t i = 1; i < ctx->n && ctx->uniform_mass; ++i) ctx->uniform_mass = host_masses[i] == ctx->mass0;
@@ -253,8 +254,8 @@ int nbody_step_allpairs(nbody_ctx* ctx, int nsteps) {
 int nbody_allpairs_partial(nbody_ctx* ctx, uint32_t part, uint32_t nparts) {
     if (!ctx) return NBODY_ERR_INVALID;
     if (!ctx->uploaded) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_allpairs_partial: no bodies uploaded");
-    if (ctx->cfg.law != NBODY_LAW_PLUMMER || ctx->cfg.integrator != NBODY_INT_WGSL_VERLET)
-        return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_allpairs_partial: only the PLUMMER law (symmetric in the pair) with the Verlet integrator");
+    if (ctx->cfg.law != NBODY_LAW_PLUMMER || ctx->cfg.integrator == NBODY_INT_CPU_EULER_XBUF)
+        return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_allpairs_partial: only the PLUMMER law (symmetric in the pair), not the cross-buffer integrator");
     if (nparts == 0 || part >= nparts) return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_allpairs_partial: part >= nparts");
     if (ctx->n < 4097) return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_allpairs_partial: needs at least two superblocks of bodies (N > 4096)");
     int r = set_device(ctx);

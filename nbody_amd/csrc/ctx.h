@@ -47,6 +47,7 @@ struct nbody_ctx {
     nbody_counters_t counters{};
     bool counting = false;
 
+    bool leapfrog_started = false;  // NBODY_INT_LEAPFROG: a step has been taken since the last upload
     // kernel timing (HIP events on `stream`)
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;  // pairs

@@ -50,7 +50,7 @@ class HipShardBackend:
     PAIR_SHARD_MIN_N = 65536
 
     def __init__(self, n, begin, count, device_index, bh_ranked=False, **cfg):
-        from .sim import NBodySim, BUF_POSM, BUF_ACC_PARTIAL, LAW_PLUMMER, INT_WGSL_VERLET
+        from .sim import NBodySim, BUF_POSM, BUF_ACC_PARTIAL, LAW_PLUMMER, INT_WGSL_VERLET, INT_CPU_EULER_XBUF
         torch.cuda.set_device(device_index)
         self.bh_ranked = bh_ranked
         self.begin, self.count = begin, count
@@ -60,7 +60,7 @@ class HipShardBackend:
             cfg = dict(cfg, shard_begin=begin, shard_count=count)
         self._buf_posm = BUF_POSM
         self._buf_partial = BUF_ACC_PARTIAL
-        self.pair_sharding = (cfg.get("law") == LAW_PLUMMER and cfg.get("integrator", INT_WGSL_VERLET) == INT_WGSL_VERLET
+        self.pair_sharding = (cfg.get("law") == LAW_PLUMMER and cfg.get("integrator", INT_WGSL_VERLET) != INT_CPU_EULER_XBUF
                               and n >= self.PAIR_SHARD_MIN_N)
         # One explicit stream carries the library's kernels AND the collectives' stream
         # dependencies.  (A null stream handle would not do: the library takes it as "create a

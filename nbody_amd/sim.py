@@ -14,7 +14,7 @@ from . import _lib
 from ._lib import NBodyConfig, NBodyCounters
 
 LAW_CPU_R6, LAW_WGSL_BIAS, LAW_PLUMMER = 0, 1, 2
-INT_CPU_EULER_XBUF, INT_WGSL_VERLET = 0, 1
+INT_CPU_EULER_XBUF, INT_WGSL_VERLET, INT_LEAPFROG = 0, 1, 2
 BUF_POSM, BUF_VEL, BUF_ACC, BUF_OCTREE, BUF_ACC_PARTIAL = 0, 1, 2, 3, 4
 NODE_DUMMY, NODE_LEAFBODY, NODE_LEAFLIST, NODE_INTERIOR = 0, 1, 2, 3
 

@@ -353,7 +353,7 @@ int nbody_accel_bh(nbody_ctx* ctx, float* host_acc16_out) {
     NB_HIP(ctx, hipMemcpyAsync(host_acc16_out + 4 * ctx->i_begin, ctx->acc_tmp + ctx->i_begin,
                                ctx->i_count * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
     NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return NBODY_OK;
+    return nb_tree_check(ctx);
 }
 
 int nbody_build_octree(nbody_ctx* ctx) {
@@ -390,7 +390,9 @@ int nbody_download(nbody_ctx* ctx, float* host_pos16, float* host_vel16, float* 
     if (!ctx->uploaded) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_download: no bodies uploaded");
     int r = set_device(ctx);
     if (r) return r;
-    return download_set(ctx, ctx->cur, host_pos16, host_vel16, host_acc16);
+    r = download_set(ctx, ctx->cur, host_pos16, host_vel16, host_acc16);
+    if (r) return r;
+    return nb_tree_check(ctx);
 }
 
 int nbody_download_alt(nbody_ctx* ctx, float* host_pos16, float* host_vel16, float* host_acc16) {
@@ -406,7 +408,7 @@ int nbody_sync(nbody_ctx* ctx) {
     int r = set_device(ctx);
     if (r) return r;
     NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return NBODY_OK;
+    return nb_tree_check(ctx);
 }
 
 int nbody_energy(nbody_ctx* ctx, double* kinetic, double* potential) {

@@ -99,6 +99,7 @@ int nb_tree_build(nbody_ctx* ctx, const float4* posm_in);
 int nb_tree_walk(nbody_ctx* ctx, const float4* posm_in, const float4* vel_in, float4* acc_out);
 int nb_tree_walk_ranked(nbody_ctx* ctx, const float4* posm_in, const float4* vel_in, float4* acc_ranked, uint64_t rank_begin,
                         uint64_t rank_count);
+int nb_tree_check(nbody_ctx* ctx);
 int nb_tree_unrank(nbody_ctx* ctx, const float4* acc_ranked, float4* acc_out);
 int nb_tree_download(nbody_ctx* ctx, nbody_octree_node* host_nodes, uint64_t cap, uint64_t* n_nodes);
 int nb_tree_upload(nbody_ctx* ctx, const nbody_octree_node* host_nodes, uint64_t n_nodes);

@@ -1051,6 +1051,14 @@ int nb_tree_walk(nbody_ctx* ctx, const float4* posm_in, const float4* vel_in, fl
     return walk_launch(ctx, T, order, m, posm_in, vel_in, acc_out, (uint32_t)ctx->i_begin, 0);
 }
 
+// Errors raised on the device by the octree kernels since the last check (capacity, traversal
+// stack); for the blocking entry points, so that a truncated traversal cannot pass unnoticed.
+int nb_tree_check(nbody_ctx* ctx) {
+    Octree* T = ctx->tree;
+    if (!T || !T->have_tree) return NBODY_OK;
+    return check_err_flag(ctx, T, "Barnes-Hut step");
+}
+
 // Targets = the bodies at sorted ranks [rank_begin, rank_begin + rank_count) of the built tree;
 // acc_ranked[rank] receives their accelerations.
 int nb_tree_walk_ranked(nbody_ctx* ctx, const float4* posm_in, const float4* vel_in, float4* acc_ranked,

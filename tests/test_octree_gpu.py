@@ -347,3 +347,57 @@ def test_ranked_forces_and_integration_equal_a_plain_step(orc):
             sim.bh_forces_ranked(n - 5, 10)       # run outside the bodies
         with pytest.raises(nb.NBodyError):
             sim.integrate_ranked()                # no octree built yet
+
+
+def _comb_tree(levels):
+    """An uploaded tree that keeps seven sibling groups pending per level: every interior node has
+    eight interior children, seven of them stubs with one leaf body each, the eighth (octant 7,
+    visited first) continuing downwards.  Ranges are huge, so a traversal opens everything."""
+    import nbody_amd as nb
+    nodes = []
+
+    def new(node_type, com=(0.0, 0.0, 0.0), mass=0.0, rng=0.0):
+        nd = np.zeros((), nb.NODE_DTYPE)
+        nd["node_type"], nd["com"], nd["total_mass"], nd["range"] = node_type, com, mass, rng
+        nd["pos_min"], nd["pos_max"] = com, com
+        nodes.append(nd)
+        return len(nodes) - 1
+
+    root = new(nb.NODE_INTERIOR, (100.0, 100.0, 100.0), 1.0, 1e6)
+    cur, leaves = root, []
+    for lvl in range(levels):
+        kids = []
+        for k in range(8):
+            c = new(nb.NODE_INTERIOR, (100.0 + lvl, 100.0 + k, 100.0), 1.0, 1e6)
+            kids.append(c)
+        nodes[cur]["child"] = kids
+        for k in range(7):
+            leaf = new(nb.NODE_LEAFBODY, (100.0 + lvl, 100.0 + k, 101.0), 1.0 + 0.01 * (lvl * 7 + k))
+            nodes[kids[k]]["child"][0] = leaf
+            leaves.append(leaf)
+        cur = kids[7]
+    last = new(nb.NODE_LEAFBODY, (90.0, 90.0, 90.0), 2.0)
+    nodes[cur]["child"][0] = last
+    return np.array(nodes, nb.NODE_DTYPE)
+
+
+def test_traversal_stack_overflow_is_an_error_not_a_wrong_answer(orc):
+    """The per-wavefront stack holds 160 pending groups, plenty for any 16-level octree; a deeper
+    uploaded tree that needs more must fail loudly at the next blocking call."""
+    import nbody_amd as nb
+    n = 64
+    m, pos = orc.gen_refcube(n, seed=2)
+    vel = np.zeros((n, 4), np.float32)
+    ok = _comb_tree(12)                       # 7 x 12 pending groups: fits
+    with nb.NBodySim(n, law=2) as sim:
+        sim.upload(m, pos)
+        sim.upload_octree(ok)
+        a = sim.accel_bh()
+    ra, _ = orc.bh_accel(2, pos, vel, ok)
+    assert body_rel_err(a, ra).max() < TOL
+    deep = _comb_tree(40)                     # 7 x 40 pending groups: does not
+    with nb.NBodySim(n, law=2) as sim:
+        sim.upload(m, pos)
+        sim.upload_octree(deep)
+        with pytest.raises(nb.NBodyError, match="stack"):
+            sim.accel_bh()

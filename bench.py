@@ -86,10 +86,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # Rehearsal on a one-GPU box: NBODY_BENCH_BACKEND=gloo NBODY_BENCH_DEVICE=0 lets several ranks
+    # share device 0 (RCCL refuses that); the numbers then mean nothing, the code path is the same.
+    backend = os.environ.get("NBODY_BENCH_BACKEND", "nccl")
+    if "NBODY_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["NBODY_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     n = args.n
     law = {"plummer": nb.LAW_PLUMMER, "wgsl_bias": nb.LAW_WGSL_BIAS}[args.law]

@@ -15,15 +15,17 @@
 //                    records where they start
 //   6. k_leaflist    depth-cap cells: sequential prefix aggregates in index order (literal
 //                    reference arithmetic, src/octree_maxdepth.rs:91-136)
-//   7. k_aggregate   bottom-up, one launch per level: mass, centre of mass, bounds, range
+//   7. k_aggregate   bottom-up, one launch per level: mass, centre of mass, bounds, range and
+//                    the acceptance thresholds derived from it
 // Node numbering differs from the reference's allocation order; the cell set, every body's leaf,
 // bounds and range are identical, masses/centres agree to rounding (different summation order).
 //
 // Traversal: one wavefront walks 64 Morton-adjacent bodies with ONE shared stack of
-// (node, lane mask) entries in LDS.  A node is opened if any lane needs it; lanes that accepted
-// an ancestor are masked out of its subtree, so each lane sees exactly the node sequence of the
-// reference's private depth-first stack (children pushed ascending, popped highest first).
-// Node records are 32 bytes and are fetched with wave-uniform (scalar) loads.
+// (first child, count, lane mask) entries in LDS.  A node is opened if any lane needs it; lanes
+// that accepted an ancestor are masked out of its subtree, so each lane interacts with exactly the
+// node SET of the reference's private depth-first stack (the order within a body's sum differs:
+// the children of a node are handled together).  Node records are 32 bytes and are fetched a
+// group at a time with wave-uniform (scalar) loads.
 #include "ctx.h"
 #include "laws.h"
 #include <algorithm>

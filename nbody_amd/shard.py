@@ -4,7 +4,8 @@ The reference is single-device.  Here the targets are split into contiguous equa
 per rank; every rank integrates its own bodies against ALL sources, then the ranks all-gather
 the packed {x,y,z,m} positions (16 bytes per body) so that each holds the sources of the next
 step.  Velocities and accelerations never leave their rank: the force laws only need the
-target's own velocity (src/nbody.wgsl:74-76).  
+target's own velocity (src/nbody.wgsl:74-76).
+
 Barnes-Hut uses REPLICATED state instead (`HipShardBackend(..., bh_ranked=True)`): every rank
 holds all N bodies and builds the same octree; rank r traverses the r-th run of the SORTED
 (Morton) order, a spatially compact set of targets whose lanes share their tree paths; the ranks
@@ -167,6 +168,8 @@ class ShardedSim:
             dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
 
     def step_allpairs(self, nsteps=1):
+        if self.world > 1 and getattr(self.backend, "bh_ranked", False):
+            raise ValueError("a bh_ranked backend holds all bodies on every rank: it is for step_bh only")
         pair = self.world > 1 and getattr(self.backend, "pair_sharding", False)
         for _ in range(nsteps):
             if pair:

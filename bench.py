@@ -197,6 +197,19 @@ def main():
                                 "ms_per_step": wdt / wsteps * 1e3, "achieved_tflops": wach,
                                 "frac": wach / PEAK_FP32_TFLOPS, "steps": wsteps}
 
+    def small_leg(nsmall, law_id, steps):
+        """All-pairs at the reference's own GPU scale (one GPU, resident inputs)."""
+        m_, p_, v_ = nb.gen_plummer(nsmall, seed=42)
+        with nb.NBodySim(nsmall, law=law_id) as s_:
+            s_.upload(m_, p_, v_)
+            s_.step_allpairs(3)
+            s_.sync()
+            t0 = time.perf_counter()
+            s_.step_allpairs(steps)
+            s_.sync()
+            sdt = time.perf_counter() - t0
+        return {"interactions_per_s": float(nsmall) * nsmall * steps / sdt, "ms_per_step": sdt / steps * 1e3, "steps": steps}
+
     def bh_leg(nbodies, bsteps, bh_law=None):
         """Barnes-Hut step, theta = 0.5, depth cap 16.  With several GPUs every rank holds all bodies:
         replicated octree build, traversal of this rank's run of the sorted (Morton) order,
@@ -258,6 +271,9 @@ def main():
                 "walk_requested_GBps_per_gpu": walk_bytes / (wms * 1e-3) / 1e9 if wms > 0 else None,
                 "equivalent_allpairs_interactions_per_s": float(nbodies) * nbodies * bsteps / bdt}
 
+    if not args.no_extras and world == 1:
+        out["allpairs_n65536"] = {"plummer": small_leg(65536, nb.LAW_PLUMMER, 50),
+                                  "wgsl_bias": small_leg(65536, nb.LAW_WGSL_BIAS, 10)}
     if not args.no_extras and args.law == "plummer":
         out["barnes_hut"] = bh_leg(n, 20)
         # the reference's traversal shader applies its acos/pow bias too (src/nbodybh.wgsl:90-101)

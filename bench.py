@@ -69,7 +69,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=1 << 20)
+    ap.add_argument("--n", "--bodies", dest="n", type=int, default=1 << 20,
+                    help="body count (use --bodies under torch.distributed.run, whose own parser claims --n)")
     ap.add_argument("--law", default="plummer", choices=["plummer", "wgsl_bias"])
     ap.add_argument("--no-extras", action="store_true", help="skip the WGSL-law and CPU-baseline legs")
     args = ap.parse_args()
@@ -152,7 +153,7 @@ def main():
     per_launch = float(n) * n / world
     achieved = per_launch * flop / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
     out = {
-        "metric": "all-pairs body-body interactions/s at N=1M",
+        "metric": "all-pairs body-body interactions/s at N=" + ("1M" if n == 1 << 20 else str(n)),
         "value": interactions / dt,
         "unit": "interactions/s",
         "n_gpus": args.gpus,

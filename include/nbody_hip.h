@@ -99,7 +99,9 @@ typedef struct nbody_config {
     uint64_t shard_begin;  /* first target body integrated by this context */
     uint64_t shard_count;  /* number of target bodies integrated by this context (0 => all) */
     int32_t device;        /* HIP device ordinal, -1 = current device */
-    int32_t reserved;
+    int32_t quadrupole;    /* opt-in, no counterpart in the reference: 1 adds each accepted cell's quadrupole
+                              moment to its monopole term in the Barnes-Hut traversal (PLUMMER law only; the
+                              acceptance test is unchanged).  0: the reference's monopole-only traversal */
     void* stream;          /* hipStream_t to enqueue on, NULL = a stream owned by the context */
 } nbody_config;
 

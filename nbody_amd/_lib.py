@@ -26,7 +26,7 @@ class NBodyConfig(C.Structure):
         ("shard_begin", C.c_uint64),
         ("shard_count", C.c_uint64),
         ("device", C.c_int32),
-        ("reserved", C.c_int32),
+        ("quadrupole", C.c_int32),
         ("stream", C.c_void_p),
     ]
 

@@ -115,6 +115,10 @@ int nbody_create(nbody_ctx** out, const nbody_config* cfg) {
         g_nbody_create_error = "nbody_create: unknown law or integrator";
         return NBODY_ERR_INVALID;
     }
+    if (cfg->quadrupole != 0 && (cfg->quadrupole != 1 || cfg->law != NBODY_LAW_PLUMMER)) {
+        g_nbody_create_error = "nbody_create: quadrupole is 0 or 1, and 1 needs the PLUMMER law";
+        return NBODY_ERR_INVALID;
+    }
     if (cfg->max_depth < 1 || cfg->max_depth > 16) {
         g_nbody_create_error = "nbody_create: max_depth must be in [1,16]";
         return NBODY_ERR_INVALID;

@@ -99,6 +99,8 @@ struct Octree {
     float4* bmax = nullptr;
     float* range = nullptr;          // longest side of that box (src/octree_maxdepth.rs:101)
     uint32_t* node_head = nullptr;   // sorted rank of the first body of each node's cell
+    float* quad = nullptr;           // opt-in: traceless quadrupole about the node's centre of mass,
+                                     // 8 floats per node {xx, xy, xz, yy, yz, zz, 0, 0}
     uint64_t cap_nodes = 0;
     uint64_t n_nodes = 0;
     bool have_tree = false;
@@ -557,6 +559,44 @@ __global__ void k_aggregate(QNode* __restrict__ nodes, float4* __restrict__ bmin
     bmax[id] = make_float4(mxx, mxy, mxz, 0.0f);
 }
 
+// ---- 7b. quadrupole moments (opt-in, no counterpart in the reference) -----------------------
+// One level, after its centres of mass are known: Q = sum over the children of
+// Q_child + m (3 d d^T - |d|^2 I), d = child centre - own centre (parallel-axis shift; a body has
+// no moment of its own).  Depth-cap cells are summed over their members when those are the bodies
+// themselves (leaflist_mode 1); the literal member lists are not bodies and get Q = 0.
+__global__ void k_quadrupole(const QNode* __restrict__ nodes, float* __restrict__ quad, uint32_t first_id, uint32_t count,
+                             int list_mode) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= count) return;
+    const uint32_t id = first_id + r;
+    const QNode nd = nodes[id];
+    const uint32_t type = qn_type(nd);
+    if (type == NBODY_NODE_LEAFBODY) return;
+    float q[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (type == NBODY_NODE_INTERIOR || (type == NBODY_NODE_LEAFLIST && list_mode)) {
+        const uint32_t c0 = nd.first, c1 = nd.first + qn_count(nd);
+        for (uint32_t c = c0; c < c1; ++c) {
+            const QNode ch = nodes[c];
+            const float dx = ch.cx - nd.cx, dy = ch.cy - nd.cy, dz = ch.cz - nd.cz;
+            const float d2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz)), m = ch.mass;
+            q[0] += m * (3.0f * dx * dx - d2);
+            q[1] += m * (3.0f * dx * dy);
+            q[2] += m * (3.0f * dx * dz);
+            q[3] += m * (3.0f * dy * dy - d2);
+            q[4] += m * (3.0f * dy * dz);
+            q[5] += m * (3.0f * dz * dz - d2);
+            if (qn_type(ch) != NBODY_NODE_LEAFBODY) {
+                const float* qc = quad + (size_t)c * 8;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) q[k] += qc[k];
+            }
+        }
+    }
+    float4* dst = reinterpret_cast<float4*>(quad + (size_t)id * 8);
+    dst[0] = make_float4(q[0], q[1], q[2], q[3]);
+    dst[1] = make_float4(q[4], q[5], 0.0f, 0.0f);
+}
+
 // ---- export / import (96-byte reference layout) ---------------------------------------------
 __global__ void k_export(const QNode* __restrict__ nodes, const float4* __restrict__ bmin, const float4* __restrict__ bmax,
                          const float* __restrict__ range, const uint32_t* __restrict__ node_head, const uint64_t* __restrict__ keys,
@@ -705,13 +745,22 @@ __device__ __forceinline__ void pin_record(const QNode& nd) {
                  "s"(nd.count_type));
 }
 
-template <int LAW, bool COUNT>
+// A node's traceless quadrupole moment about its centre of mass (opt-in), 32 B like the record.
+struct QMoment {
+    float xx, xy, xz, yy, yz, zz, pad0, pad1;
+};
+__device__ __forceinline__ void pin_moment(const QMoment& m) {
+    asm volatile("" ::"s"(m.xx), "s"(m.xy), "s"(m.xz), "s"(m.yy), "s"(m.yz), "s"(m.zz));
+}
+
+template <int LAW, bool COUNT, bool QUAD>
 __global__ __launch_bounds__(WALK_THREADS) void k_walk(const QNode* __restrict__ q, const uint32_t* __restrict__ order, uint32_t m,
                                               uint32_t i_begin, const float4* __restrict__ posm,
                                               const float4* __restrict__ vel, float4* __restrict__ acc_out, float G,
                                               float eps2, float theta, const float* __restrict__ range,
                                               unsigned long long* __restrict__ counters,
-                                              uint32_t* __restrict__ err_flag, int out_by_rank) {
+                                              uint32_t* __restrict__ err_flag, int out_by_rank,
+                                              const float* __restrict__ quad) {
     // Target r of this launch is body order[r] (or i_begin + r without an order); its result goes
     // to acc_out[body], or with out_by_rank to acc_out[i_begin + r].
     __shared__ uint4 st[WALK_THREADS / 64][WALK_STACK];  // {first, count, mask.lo, mask.hi}
@@ -749,23 +798,35 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk(const QNode* __restrict__
         const uint32_t mlo = (uint32_t)__builtin_amdgcn_readfirstlane(e.z);
         const uint32_t mhi = (uint32_t)__builtin_amdgcn_readfirstlane(e.w);
         const unsigned long long mask = ((unsigned long long)mhi << 32) | (unsigned long long)mlo;
-        for (uint32_t b0 = 0; b0 < cnt; b0 += WALK_BATCH) {
-            const uint32_t nb = min((uint32_t)WALK_BATCH, cnt - b0);
+        // with quadrupoles the moments ride along with the records: half the batch, same registers
+        constexpr int BATCH = QUAD ? WALK_BATCH / 2 : WALK_BATCH;
+        for (uint32_t b0 = 0; b0 < cnt; b0 += BATCH) {
+            const uint32_t nb = min((uint32_t)BATCH, cnt - b0);
             // All records of the batch are fetched before the first use, from consecutive
             // addresses whether the group has that many or not (the array is padded).
-            QNode c[WALK_BATCH];
+            QNode c[BATCH];
+            QMoment qm[QUAD ? BATCH : 1];
             const QNode* group = q + (first + b0);
 #pragma unroll
-            for (int k = 0; k < WALK_BATCH; ++k) c[k] = group[k];
+            for (int k = 0; k < BATCH; ++k) c[k] = group[k];
+            if (QUAD) {
+                const QMoment* gq = reinterpret_cast<const QMoment*>(quad) + (first + b0);
 #pragma unroll
-            for (int k = 0; k < WALK_BATCH; ++k) pin_record(c[k]);
-            if (top + WALK_BATCH > WALK_STACK) {
+                for (int k = 0; k < BATCH; ++k) qm[k] = gq[k];
+            }
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k) pin_record(c[k]);
+            if (QUAD) {
+#pragma unroll
+                for (int k = 0; k < BATCH; ++k) pin_moment(qm[k]);
+            }
+            if (top + BATCH > WALK_STACK) {
                 if (lane == 0) *err_flag = 2;
                 top = 0;
                 break;
             }
 #pragma unroll
-            for (int k = 0; k < WALK_BATCH; ++k) {
+            for (int k = 0; k < BATCH; ++k) {
                 if ((uint32_t)k >= nb) break;
                 const QNode nd = c[k];
                 if (COUNT) {
@@ -804,11 +865,35 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk(const QNode* __restrict__
                 }
                 if (take) {
                     // every lane evaluates the term; lanes that do not take it add zero
-                    const float sc = pair_scale<LAW, WALK_PRECISE>(t, dx, dy, dz, r2, nd.mass, eps2);
+                    float ri = 0.0f;  // QUAD (PLUMMER law only): 1/R shared by the monopole and quadrupole terms
+                    float sc;
+                    if (QUAD) {
+                        ri = __builtin_amdgcn_rsqf(r2 + eps2);
+                        sc = (nd.mass * ri) * (ri * ri);
+                    } else {
+                        sc = pair_scale<LAW, WALK_PRECISE>(t, dx, dy, dz, r2, nd.mass, eps2);
+                    }
                     const float w = __builtin_amdgcn_inverse_ballot_w64(take) ? sc : 0.0f;
                     ax = fmaf(w, dx, ax);
                     ay = fmaf(w, dy, ay);
                     az = fmaf(w, dz, az);
+                    if (QUAD && qn_type(nd) != NBODY_NODE_LEAFBODY) {
+                        // quadrupole term of an accepted cell (d = centre - target, R^2 = r^2 + eps2):
+                        // -Q d / R^5 + 5/2 (d.Q d) d / R^7
+                        const QMoment& mo = qm[QUAD ? k : 0];
+                        const float qxx = mo.xx, qxy = mo.xy, qxz = mo.xz, qyy = mo.yy, qyz = mo.yz, qzz = mo.zz;
+                        const float ri2 = ri * ri;
+                        const float ri5 = (ri2 * ri2) * ri, ri7 = ri5 * ri2;
+                        const float ux = fmaf(qxx, dx, fmaf(qxy, dy, qxz * dz));
+                        const float uy = fmaf(qxy, dx, fmaf(qyy, dy, qyz * dz));
+                        const float uz = fmaf(qxz, dx, fmaf(qyz, dy, qzz * dz));
+                        const float dqd = fmaf(dx, ux, fmaf(dy, uy, dz * uz));
+                        const bool on = __builtin_amdgcn_inverse_ballot_w64(take);
+                        const float c1 = on ? -ri5 : 0.0f, c2 = on ? 2.5f * dqd * ri7 : 0.0f;
+                        ax = fmaf(c1, ux, fmaf(c2, dx, ax));
+                        ay = fmaf(c1, uy, fmaf(c2, dy, ay));
+                        az = fmaf(c1, uz, fmaf(c2, dz, az));
+                    }
                 }
             }
         }
@@ -847,6 +932,11 @@ int ensure_nodes(nbody_ctx* ctx, Octree* T, uint64_t need) {
     // the traversal fetches whole batches: pad so that the last group's batch stays inside
     NB_HIP(ctx, hipMalloc(&T->nodes, (cap + WALK_BATCH) * sizeof(QNode)));
     NB_HIP(ctx, hipMalloc(&T->range, cap * sizeof(float)));
+    if (ctx->cfg.quadrupole) {
+        if (T->quad) NB_HIP(ctx, hipFree(T->quad));
+        T->quad = nullptr;
+        NB_HIP(ctx, hipMalloc(&T->quad, (cap + WALK_BATCH) * 8 * sizeof(float)));
+    }
     NB_HIP(ctx, hipMalloc(&T->node_head, cap * sizeof(uint32_t)));
     NB_HIP(ctx, hipMalloc(&T->bmin, cap * sizeof(float4)));
     NB_HIP(ctx, hipMalloc(&T->bmax, cap * sizeof(float4)));
@@ -872,14 +962,19 @@ template <int LAW>
 void launch_walk(nbody_ctx* ctx, Octree* T, const uint32_t* order, uint32_t m, const float4* posm, const float4* vel,
                  float4* acc_out, uint32_t i_begin, int out_by_rank) {
     dim3 grid((m + WALK_THREADS - 1) / WALK_THREADS);
-    if (ctx->counting)
-        hipLaunchKernelGGL((k_walk<LAW, true>), grid, dim3(WALK_THREADS), 0, ctx->stream, T->nodes, order, m, i_begin,
-                           posm, vel, acc_out, ctx->cfg.G, ctx->cfg.eps2, ctx->cfg.theta, T->range,
-                           (unsigned long long*)T->walk_counters, T->err_flag, out_by_rank);
-    else
-        hipLaunchKernelGGL((k_walk<LAW, false>), grid, dim3(WALK_THREADS), 0, ctx->stream, T->nodes, order, m, i_begin,
-                           posm, vel, acc_out, ctx->cfg.G, ctx->cfg.eps2, ctx->cfg.theta, T->range,
-                           (unsigned long long*)T->walk_counters, T->err_flag, out_by_rank);
+    const bool quad = T->quad != nullptr && T->built;  // uploaded trees carry no moments
+#define NB_WALK(COUNT, QUAD)                                                                                              \
+    hipLaunchKernelGGL((k_walk<LAW, COUNT, QUAD>), grid, dim3(WALK_THREADS), 0, ctx->stream, T->nodes, order, m, i_begin, posm, \
+                       vel, acc_out, ctx->cfg.G, ctx->cfg.eps2, ctx->cfg.theta, T->range,                                 \
+                       (unsigned long long*)T->walk_counters, T->err_flag, out_by_rank, T->quad)
+    if (ctx->counting) {
+        if (quad) NB_WALK(true, true);
+        else NB_WALK(true, false);
+    } else {
+        if (quad) NB_WALK(false, true);
+        else NB_WALK(false, false);
+    }
+#undef NB_WALK
 }
 
 }  // namespace
@@ -925,7 +1020,7 @@ void nb_tree_destroy(nbody_ctx* ctx) {
         if (T->idx[s]) hipFree(T->idx[s]);
     }
     void* ptrs[] = {T->lo, T->top, T->flags, T->body_node, T->rs_counts, T->row_total, T->blk,
-                    T->lvl_total, T->lvl_start, T->nodes, T->node_head, T->bmin, T->bmax, T->range, T->export_buf, T->shard_order, T->shard_blk,
+                    T->lvl_total, T->lvl_start, T->nodes, T->node_head, T->bmin, T->bmax, T->range, T->quad, T->export_buf, T->shard_order, T->shard_blk,
                     T->walk_counters, T->err_flag};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -996,6 +1091,14 @@ int nb_tree_build(nbody_ctx* ctx, const float4* posm_in) {
         // the children of level d are the nodes of level d + 1
         hipLaunchKernelGGL(k_aggregate, dim3((count + 255) / 256), dim3(256), 0, st, T->nodes, T->bmin, T->bmax, T->range, first,
                            count, T->h_lvl_start[d + 2], mac);
+    }
+    if (T->quad) {
+        for (int d = D; d >= 0; --d) {
+            const uint32_t first = T->h_lvl_start[d], count = T->h_lvl_start[d + 1] - first;
+            if (!count) continue;
+            hipLaunchKernelGGL(k_quadrupole, dim3((count + 255) / 256), dim3(256), 0, st, T->nodes, T->quad, first, count,
+                               ctx->cfg.leaflist_mode);
+        }
     }
     nb_time_end(ctx, 2);
     NB_HIP(ctx, hipGetLastError());

@@ -401,3 +401,58 @@ def test_traversal_stack_overflow_is_an_error_not_a_wrong_answer(orc):
         sim.upload_octree(deep)
         with pytest.raises(nb.NBodyError, match="stack"):
             sim.accel_bh()
+
+
+def test_quadrupole_option_tightens_the_force_error(orc):
+    """Opt-in quadrupole moments (no counterpart in the reference): same tree, same acceptance
+    decisions, and the error against the direct sum drops by a large factor."""
+    import nbody_amd as nb
+    n = 20000
+    m, pos, _ = nb.gen_plummer(n, seed=13)
+    vel = np.zeros((n, 4), np.float32)
+    exact = orc.accel_allpairs_f64(orc.LAW_PLUMMER, pos, vel, m)
+
+    def run(quadrupole):
+        with nb.NBodySim(n, law=nb.LAW_PLUMMER, quadrupole=quadrupole, leaflist_mode=1) as sim:
+            sim.upload(m, pos)
+            sim.build_octree()
+            sim.set_counting(True)
+            a = sim.accel_bh()
+            return a, sim.counters()
+
+    a0, c0 = run(0)
+    a1, c1 = run(1)
+    for k in ("bh_node_visits", "bh_leaf_interactions", "bh_aggregate_interactions", "octree_nodes"):
+        assert c0[k] == c1[k]
+    scale = np.linalg.norm(exact, axis=1)
+    e0 = np.linalg.norm(a0[:, :3] - exact, axis=1) / scale
+    e1 = np.linalg.norm(a1[:, :3] - exact, axis=1) / scale
+    print(f"median / 99th percentile relative force error: monopole {np.median(e0):.2e} / {np.quantile(e0, 0.99):.2e}, "
+          f"with quadrupoles {np.median(e1):.2e} / {np.quantile(e1, 0.99):.2e}")
+    # cells are accepted up to range/distance = 0.5, so the next multipole order gains a factor ~2
+    assert np.median(e1) < 0.65 * np.median(e0)
+    assert np.quantile(e1, 0.99) < 0.65 * np.quantile(e0, 0.99)
+    with pytest.raises(nb.NBodyError):
+        nb.NBodySim(n, law=nb.LAW_WGSL_BIAS, quadrupole=1)
+
+
+def test_quadrupole_of_a_far_cluster_matches_the_direct_sum(orc):
+    """One tight cluster seen from far away: monopole error ~ (s/r)^2, with the quadrupole ~ (s/r)^3."""
+    import nbody_amd as nb
+    rng = np.random.default_rng(3)
+    k = 64
+    pos = np.zeros((k + 1, 4), np.float32)
+    pos[:k, :3] = 60.0 + rng.uniform(-1.0, 1.0, (k, 3)) * np.array([1.0, 0.4, 0.2])   # an elongated clump
+    pos[k, :3] = (200.0, 180.0, 190.0)                                               # the far target
+    m = np.concatenate([rng.uniform(0.5, 8.0, k), [1.0]]).astype(np.float32)
+    vel = np.zeros_like(pos)
+    exact = orc.accel_allpairs_f64(orc.LAW_PLUMMER, pos, vel, m)[k]
+    err = []
+    for quadrupole in (0, 1):
+        with nb.NBodySim(k + 1, law=nb.LAW_PLUMMER, quadrupole=quadrupole, leaflist_mode=1) as sim:
+            sim.upload(m, pos)
+            sim.build_octree()
+            a = sim.accel_bh()[k, :3]
+        err.append(np.linalg.norm(a - exact) / np.linalg.norm(exact))
+    print('far cluster, relative error: monopole %.2e, with quadrupole %.2e' % tuple(err))
+    assert err[1] < 0.05 * err[0] and err[1] < 5e-6, err

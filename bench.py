@@ -72,7 +72,10 @@ def main():
     ap.add_argument("--n", "--bodies", dest="n", type=int, default=1 << 20,
                     help="body count (use --bodies under torch.distributed.run, whose own parser claims --n)")
     ap.add_argument("--law", default="plummer", choices=["plummer", "wgsl_bias"])
-    ap.add_argument("--no-extras", action="store_true", help="skip the WGSL-law and CPU-baseline legs")
+    ap.add_argument("--no-extras", action="store_true", help="skip the WGSL-law, Barnes-Hut and CPU-baseline legs")
+    ap.add_argument("--config2", action="store_true",
+                    help="add all-pairs legs at N=65536 (they launch the headline kernel too, which would blur its "
+                         "average in a profile of this command, so they are off by default)")
     args = ap.parse_args()
 
     import torch
@@ -272,7 +275,7 @@ def main():
                 "walk_requested_GBps_per_gpu": walk_bytes / (wms * 1e-3) / 1e9 if wms > 0 else None,
                 "equivalent_allpairs_interactions_per_s": float(nbodies) * nbodies * bsteps / bdt}
 
-    if not args.no_extras and world == 1:
+    if args.config2 and world == 1:
         out["allpairs_n65536"] = {"plummer": small_leg(65536, nb.LAW_PLUMMER, 50),
                                   "wgsl_bias": small_leg(65536, nb.LAW_WGSL_BIAS, 10)}
     if not args.no_extras and args.law == "plummer":

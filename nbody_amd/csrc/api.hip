@@ -119,8 +119,8 @@ int nbody_create(nbody_ctx** out, const nbody_config* cfg) {
         g_nbody_create_error = "nbody_create: quadrupole is 0 or 1, and 1 needs the PLUMMER law";
         return NBODY_ERR_INVALID;
     }
-    if (cfg->max_depth < 1 || cfg->max_depth > 16) {
-        g_nbody_create_error = "nbody_create: max_depth must be in [1,16]";
+    if (cfg->max_depth > 16) {
+        g_nbody_create_error = "nbody_create: max_depth must be in [1,16], or 0 for the uncapped src/octree.rs variant";
         return NBODY_ERR_INVALID;
     }
     uint64_t sc = cfg->shard_count ? cfg->shard_count : cfg->n_bodies - cfg->shard_begin;

@@ -105,6 +105,7 @@ struct Octree {
     uint64_t n_nodes = 0;
     bool have_tree = false;
     bool built = false;  // tree came from nb_tree_build (keys/order valid)
+    bool octree_rs = false;  // export in the layout of src/octree.rs (is_leaf, max_depth); no leaf lists
     // export buffer
     nbody_octree_node* export_buf = nullptr;
     uint64_t export_cap = 0;
@@ -600,7 +601,8 @@ __global__ void k_quadrupole(const QNode* __restrict__ nodes, float* __restrict_
 // ---- export / import (96-byte reference layout) ---------------------------------------------
 __global__ void k_export(const QNode* __restrict__ nodes, const float4* __restrict__ bmin, const float4* __restrict__ bmax,
                          const float* __restrict__ range, const uint32_t* __restrict__ node_head, const uint64_t* __restrict__ keys,
-                         const uint32_t* __restrict__ lvl_start, int D, uint32_t count, nbody_octree_node* __restrict__ out) {
+                         const uint32_t* __restrict__ lvl_start, int D, uint32_t count, int octree_rs,
+                         nbody_octree_node* __restrict__ out) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= count) return;
     const QNode nd = nodes[id];
@@ -627,6 +629,18 @@ __global__ void k_export(const QNode* __restrict__ nodes, const float4* __restri
     }
     o.node_type = type;
     o.depth = (uint32_t)depth;
+    if (octree_rs) {
+        // src/octree.rs:5-15: is_leaf where the capped builder has node_type, and max_depth, which
+        // only the root carries (:36): the value returned for the deepest leaf (:58) = its depth + 1
+        o.node_type = type == NBODY_NODE_LEAFBODY ? 1u : 0u;
+        o.depth = 0;
+        if (id == 0) {
+            int deepest = 0;
+            for (int d = 0; d <= D; ++d)
+                if (lvl_start[d + 1] > lvl_start[d]) deepest = d;
+            o.depth = (uint32_t)deepest + 1u;
+        }
+    }
     o._pad2 = 0;
     out[id] = o;
 }
@@ -983,7 +997,9 @@ int nb_tree_create(nbody_ctx* ctx) {
     Octree* T = new Octree;
     ctx->tree = T;
     T->n = ctx->n;
-    T->D = ctx->cfg.max_depth;
+    // max_depth 0: the uncapped builder of src/octree.rs, reproduced as far as 16 levels reach
+    T->D = ctx->cfg.max_depth ? ctx->cfg.max_depth : 16;
+    T->octree_rs = ctx->cfg.max_depth == 0;
     const uint64_t n = T->n;
     T->rs_nb = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
     T->pf_nb = (uint32_t)((n + 255) / 256);
@@ -1079,6 +1095,15 @@ int nb_tree_build(nbody_ctx* ctx, const float4* posm_in) {
         NB_HIP(ctx, hipGetLastError());
     }
     T->n_nodes = total;
+    if (T->octree_rs && T->h_lvl_start[LIST_ROW + 1] > T->h_lvl_start[LIST_ROW]) {
+        // list members exist: two bodies share a level-16 cell, where the uncapped builder would
+        // descend further (or, for coincident bodies, never end)
+        NB_HIP(ctx, hipStreamSynchronize(st));
+        T->have_tree = false;
+        nb_time_end(ctx, 2);
+        return nb_fail(ctx, NBODY_ERR_CAPACITY,
+                       "octree.rs variant (max_depth 0): two bodies share a level-16 cell, beyond the 16 levels reproduced");
+    }
     if (T->h_lvl_start[LIST_ROW + 1] > T->h_lvl_start[LIST_ROW] || T->h_lvl_start[D + 1] > T->h_lvl_start[D]) {
         hipLaunchKernelGGL(k_leaflist, dim3((n + 255) / 256), dim3(256), 0, st, T->keys[cur], T->idx[cur], posm_in, n,
                            ctx->cfg.leaflist_mode, T->flags, T->body_node, T->nodes, T->bmin, T->bmax, T->range, T->node_head,
@@ -1215,7 +1240,8 @@ int nb_tree_device_nodes(nbody_ctx* ctx, void** ptr, size_t* bytes) {
     const uint32_t cnt = (uint32_t)T->n_nodes;
     if (!T->export_is_upload) {  // an uploaded tree is kept as it came (renumbered); a built one is exported
         hipLaunchKernelGGL(k_export, dim3((cnt + 255) / 256), dim3(256), 0, ctx->stream, T->nodes, T->bmin, T->bmax,
-                           T->range, T->node_head, T->keys[T->sorted], T->lvl_start, (int)T->D, cnt, T->export_buf);
+                           T->range, T->node_head, T->keys[T->sorted], T->lvl_start, (int)T->D, cnt, T->octree_rs ? 1 : 0,
+                           T->export_buf);
         NB_HIP(ctx, hipGetLastError());
     }
     *ptr = T->export_buf;

@@ -456,3 +456,53 @@ def test_quadrupole_of_a_far_cluster_matches_the_direct_sum(orc):
         err.append(np.linalg.norm(a - exact) / np.linalg.norm(exact))
     print('far cluster, relative error: monopole %.2e, with quadrupole %.2e' % tuple(err))
     assert err[1] < 0.05 * err[0] and err[1] < 5e-6, err
+
+
+@pytest.mark.parametrize("name", ["refcube250", "refcube4096", "plummer20000"])
+def test_uncapped_octree_rs_variant(orc, name):
+    """max_depth = 0: the dormant builder of src/octree.rs -- same cells, is_leaf at offset 84,
+    max_depth on the root (src/octree.rs:36,58), as long as 16 levels separate all bodies."""
+    import nbody_amd as nb
+    m, pos = dataset(orc, name)
+    ref_nodes, leaf, dep, md = orc.build_octree(pos, m, variant=1)
+    assert dep.max() < 16
+    with nb.NBodySim(len(m), max_depth=0) as sim:
+        sim.upload(m, pos)
+        sim.build_octree()
+        nodes = sim.download_octree()
+        keys, depth, _ = sim.morton_keys()
+    assert np.array_equal(depth, dep)
+    assert len(nodes) == len(ref_nodes)
+    assert nodes[0]["depth"] == md == ref_nodes[0]["max_depth"]          # the max_depth field of the root
+    assert not nodes[1:]["depth"].any()
+
+    def cells(ns):
+        out, stack = {}, [(0, ())]
+        while stack:
+            idx, path = stack.pop()
+            out[path] = ns[idx]
+            if not ns[idx]["node_type"]:                              # is_leaf == 0
+                stack += [(int(c), path + (k,)) for k, c in enumerate(ns[idx]["child"]) if c]
+        return out
+
+    g, r = cells(nodes), cells(ref_nodes)
+    assert set(g) == set(r)
+    for path, rn in r.items():
+        gn = g[path]
+        assert gn["node_type"] == rn["node_type"]
+        assert np.array_equal(gn["pos_min"], rn["pos_min"]) and np.array_equal(gn["pos_max"], rn["pos_max"])
+        assert gn["range"] == rn["range"]
+        if rn["node_type"]:
+            assert np.array_equal(gn["com"], rn["com"]) and gn["total_mass"] == rn["total_mass"]
+        else:
+            assert abs(gn["total_mass"] - rn["total_mass"]) <= 2e-4 * rn["total_mass"]
+
+
+def test_uncapped_variant_refuses_what_16_levels_cannot_separate(orc):
+    import nbody_amd as nb
+    pos = p4([[10, 10, 10], [10, 10, 10 + 250.0 / 65536 / 8], [200, 100, 50]])
+    m = np.ones(3, np.float32)
+    with nb.NBodySim(3, max_depth=0) as sim:
+        sim.upload(m, pos)
+        with pytest.raises(nb.NBodyError, match="level-16"):
+            sim.build_octree()

@@ -87,3 +87,30 @@ def test_generators_match_numpy(orc):
     speed = np.linalg.norm(v[:, :3], axis=1)
     vesc = np.sqrt(2 * 0.0066743 * 4515.625 / 12.5) * (1 + (r / 12.5) ** 2) ** -0.25
     assert np.all(speed <= vesc * 1.0001) and speed.mean() > 0.2 * vesc.mean()
+
+
+def test_rust_bindings_cover_the_header():
+    """rust/nbody-hip-sys cannot be compiled in this image; at least it must bind every function
+    of the header, each with the header's number of parameters, and mirror the struct fields."""
+    text = open(os.path.join(ROOT, "include", "nbody_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    rust = open(os.path.join(ROOT, "rust", "nbody-hip-sys", "src", "lib.rs")).read()
+    rust = re.sub(r"//[^\n]*", "", rust)
+
+    def nparams(args):
+        args = args.strip()
+        return 0 if args in ("", "void") else args.count(",") + 1
+
+    header = {m.group(1): nparams(m.group(2)) for m in re.finditer(r"\b(nbody_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text)}
+    bound = {m.group(1): nparams(m.group(2)) for m in re.finditer(r"pub fn (nbody_[a-z0-9_]+)\s*\(([^)]*)\)", rust)}
+    assert set(header) == set(declared_symbols())
+    assert bound == header
+    # struct fields in declaration order (the C names, except G which Rust spells g)
+    cfg_c = re.search(r"typedef struct nbody_config \{(.*?)\} nbody_config;", text, re.S).group(1)
+    cfg_fields = [f.lower() for f in re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*;", cfg_c)]
+    cfg_rust = re.search(r"pub struct nbody_config \{(.*?)\}", rust, re.S).group(1)
+    assert re.findall(r"pub ([a-z0-9_]+):", cfg_rust) == cfg_fields
+    for name in ("NBODY_LAW_PLUMMER", "NBODY_INT_LEAPFROG", "NBODY_BUF_ACC_PARTIAL", "NBODY_ERR_NOMEM", "NBODY_NODE_INTERIOR"):
+        c_val = int(re.search(name + r"\s*=\s*(-?\d+)", text).group(1))
+        r_val = int(re.search(r"pub const " + name + r": [a-z0-9_]+ = (-?\d+);", rust).group(1))
+        assert c_val == r_val, name

@@ -779,7 +779,12 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk(const QNode* __restrict__
     // to acc_out[body], or with out_by_rank to acc_out[i_begin + r].
     __shared__ uint4 st[WALK_THREADS / 64][WALK_STACK];  // {first, count, mask.lo, mask.hi}
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t r = blockIdx.x * WALK_THREADS + tid;
+    // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2): give each XCD one
+    // contiguous eighth of the Morton order, so that it keeps meeting the same part of the tree.
+    const uint32_t nblk = gridDim.x, q8 = nblk / 8, r8 = nblk % 8;
+    const uint32_t xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
+    const uint32_t blk = xcd * q8 + min(xcd, r8) + slot;
+    const uint32_t r = blk * WALK_THREADS + tid;
     const bool valid = r < m;
     const uint32_t b = valid ? (order ? order[r] : i_begin + r) : 0u;
     Tgt t;

@@ -403,6 +403,16 @@ __global__ void k_energy(const float4* __restrict__ posm, const float4* __restri
     }
 }
 
+int env_int(const char* name, int dflt);
+// targets per lane of the pair kernel (superblock = 256 of them)
+static int sym_tpl() {
+    // 16: the per-step work that does not depend on the target count (the reaction's LDS
+    // read-add-write and its adds) is spread over twice the pairs; measured 5 % faster than 8 at
+    // 2 wavefronts per SIMD instead of 4, while 32 (1 wavefront, spills) is slower
+    const int t = env_int("NBODY_AP_SYM_TPL", 16);
+    return t == 4 || t == 8 ? t : 16;
+}
+
 int env_int(const char* name, int dflt) {
     const char* s = getenv(name);
     return s ? atoi(s) : dflt;
@@ -503,7 +513,7 @@ int nb_allpairs_diag(nbody_ctx* ctx, const float4* posm_in, float4* diag_out, in
 
 // One part's share of the pair tiles of ALL bodies (PLUMMER): acc_tmp[j] for every j.
 int nb_allpairs_partial(nbody_ctx* ctx, uint32_t part, uint32_t nparts) {
-    const int tpl = env_int("NBODY_AP_SYM_TPL", 8) == 4 ? 4 : 8;
+    const int tpl = sym_tpl();
     const uint64_t nsb = (ctx->n + 256 * tpl - 1) / (256 * tpl), nt = (ctx->n + 63) / 64;
     uint32_t seg = (uint32_t)std::min<uint64_t>(512, std::max<uint64_t>(4, nsb * nt / 2 / 32768));
     if (env_int("NBODY_AP_SEG", 0) > 0) seg = (uint32_t)env_int("NBODY_AP_SEG", 0);
@@ -519,7 +529,7 @@ int nb_allpairs_forces(nbody_ctx* ctx, const float4* posm_in, const float4* vel_
     if (law == NBODY_LAW_PLUMMER && ctx->i_count == ctx->n && sym_env != 0 &&
         ctx->n >= (sym_env == 1 ? 4097u : 65536u)) {
         // one evaluation per unordered pair; needs (superblocks x n / 2) x 16 B of partial rows
-        const int tpl = env_int("NBODY_AP_SYM_TPL", 8) == 4 ? 4 : 8;
+        const int tpl = sym_tpl();
         // work items of `seg` source tiles each: aim at ~32K items (measured best at N = 1M)
         const uint64_t nsb = (ctx->n + 256 * tpl - 1) / (256 * tpl), nt = (ctx->n + 63) / 64;
         uint32_t seg = (uint32_t)std::min<uint64_t>(512, std::max<uint64_t>(4, nsb * nt / 2 / 32768));

@@ -2,22 +2,22 @@
 //
 // The plain kernel (allpairs.hip) spends 12 packed lane-ops + 1 v_rsq_f32 per ordered pair.  The
 // distance, r^2 and r^-3 of a pair serve both bodies; what differs is the mass factor and the sign.
-// Bodies are grouped in superblocks of 1024 (one workgroup: 4 wavefronts x 64 lanes x 4 targets
-// held in registers, two per packed register pair).  A work item is (superblock a, a run of
-// 64-body source tiles that lie in LATER superblocks).  Per source tile every lane meets each of
-// the 64 sources once: at step t lane l reads source (l + t) mod 64 from LDS (conflict-free),
-// updates its four targets' accelerations in registers, and adds the four reactions on that
-// source to the wavefront's own LDS accumulator by a plain read-add-write (lane-distinct
-// addresses, one wavefront per accumulator, LDS operations of a wavefront execute in order;
-// ds_add_f32 was measured an order of magnitude slower here).  After the tile the four wavefronts' accumulators are
-// summed in a fixed order and written as that item's partial row; a final kernel adds, per body
+// Bodies are grouped in superblocks of 256 * P (one workgroup: 4 wavefronts x 64 lanes x P targets
+// held in registers, two per packed register pair; P = 16 by default).  A work item is
+// (superblock a, a run of 64-body source tiles that lie in LATER superblocks).  Per source tile
+// every lane meets each of the 64 sources once: at step t lane l reads source (l + t) mod 64 from
+// LDS (conflict-free), updates its P targets' accelerations in registers, and adds the P
+// reactions on that source to the wavefront's own LDS accumulator by a plain read-add-write
+// (lane-distinct addresses, one wavefront per accumulator, LDS operations of a wavefront execute
+// in order; ds_add_f32 was measured an order of magnitude slower here).  After the tile the four
+// wavefronts' accumulators are summed in a fixed order and written as that item's partial row; a final kernel adds, per body
 // and in a fixed order, the partial rows of all earlier superblocks, the target-side partials of
 // its own superblock's items and the within-superblock term.  No atomics reach global memory, so
 // results are reproducible bit for bit.
 //
-// Per step (8 pair-interactions = 16 ordered interactions) a lane issues 32 v_pk_*_f32,
-// 4 v_rsq_f32 and 3 v_add_f32: about 21 cycles per ordered interaction against 34 for the plain
-// kernel.
+// Per step (P pair-interactions = 2 P ordered interactions) a lane issues 7 P v_pk_*_f32,
+// P v_rsq_f32 and 7 instructions that do not depend on P (the reaction's adds): about 18 cycles
+// per ordered interaction at P = 16 against 34 for the plain kernel.
 #include "ctx.h"
 #include <algorithm>
 #include <cstdlib>
@@ -353,12 +353,12 @@ static int sym_prepare(nbody_ctx* ctx, uint32_t seg_tiles, uint32_t SB) {
     return NBODY_OK;
 }
 
-// PLUMMER forces on all n bodies.  tpl: targets per lane (4 or 8).  part/nparts: evaluate every
+// PLUMMER forces on all n bodies.  tpl: targets per lane (4, 8 or 16).  part/nparts: evaluate every
 // nparts-th work item only; acc_out then holds this part's contribution to EVERY body (the
 // within-superblock term only for the context's own targets) and the parts must be summed.
 int nb_allpairs_forces_sym(nbody_ctx* ctx, const float4* posm_in, float4* acc_out, uint32_t seg_tiles, int tpl,
                            uint32_t part, uint32_t nparts) {
-    tpl = (tpl == 8) ? 8 : 4;
+    tpl = (tpl == 16 || tpl == 8) ? tpl : 4;
     const uint32_t SB = 256u * (uint32_t)tpl;
     int r = sym_prepare(ctx, seg_tiles, SB);
     if (r) return r;
@@ -370,7 +370,9 @@ int nb_allpairs_forces_sym(nbody_ctx* ctx, const float4* posm_in, float4* acc_ou
 #define NB_SYM_LAUNCH(U, T)                                                                                          \
     hipLaunchKernelGGL((k_ap_sym<U, T>), dim3((P->n_items + nparts - 1) / nparts), dim3(256), 0, ctx->stream, posm_in, n, \
                        P->items, P->rowoff, P->part_j, P->part_i, ctx->cfg.eps2, part, nparts, P->n_items)
-        if (uniform && tpl == 8) NB_SYM_LAUNCH(true, 8);
+        if (uniform && tpl == 16) NB_SYM_LAUNCH(true, 16);
+        else if (tpl == 16) NB_SYM_LAUNCH(false, 16);
+        else if (uniform && tpl == 8) NB_SYM_LAUNCH(true, 8);
         else if (uniform) NB_SYM_LAUNCH(true, 4);
         else if (tpl == 8) NB_SYM_LAUNCH(false, 8);
         else NB_SYM_LAUNCH(false, 4);

@@ -156,7 +156,8 @@ int nbody_upload_alt(nbody_ctx* ctx, const float* host_pos16, const float* host_
  * accepted: the host must all-gather NBODY_BUF_POSM between steps. */
 int nbody_step_allpairs(nbody_ctx* ctx, int nsteps);
 /* Replaces one tick of src/nbody_gpu_bh.rs:445-527: octree build from the current positions,
- * traversal, integration with clamp to [0,world]^3, swap. */
+ * traversal, integration with clamp to [0,world]^3, swap.  The laws are those of
+ * src/nbodybh.wgsl (NBODY_LAW_CPU_R6 and NBODY_INT_CPU_EULER_XBUF are refused: NBODY_ERR_INVALID). */
 int nbody_step_bh(nbody_ctx* ctx, int nsteps);
 
 /* Multi-GPU all-pairs with ONE evaluation per unordered pair (PLUMMER law, Verlet).  The pair

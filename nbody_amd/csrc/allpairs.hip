@@ -403,9 +403,13 @@ __global__ void k_energy(const float4* __restrict__ posm, const float4* __restri
     }
 }
 
-int env_int(const char* name, int dflt);
+int env_int(const char* name, int dflt) {
+    const char* s = getenv(name);
+    return s ? atoi(s) : dflt;
+}
+
 // targets per lane of the pair kernel (superblock = 256 of them)
-static int sym_tpl() {
+int sym_tpl() {
     // 16: the per-step work that does not depend on the target count (the reaction's LDS
     // read-add-write and its adds) is spread over twice the pairs; measured 5 % faster than 8 at
     // 2 wavefronts per SIMD instead of 4, while 32 (1 wavefront, spills) is slower
@@ -413,9 +417,11 @@ static int sym_tpl() {
     return t == 4 || t == 8 ? t : 16;
 }
 
-int env_int(const char* name, int dflt) {
-    const char* s = getenv(name);
-    return s ? atoi(s) : dflt;
+// source tiles per work item of the pair kernel: aim at ~32K items (measured best at N = 1M)
+uint32_t sym_seg_tiles(const nbody_ctx* ctx, int tpl) {
+    if (env_int("NBODY_AP_SEG", 0) > 0) return (uint32_t)env_int("NBODY_AP_SEG", 0);
+    const uint64_t nsb = (ctx->n + 256 * tpl - 1) / (256 * tpl), nt = (ctx->n + 63) / 64;
+    return (uint32_t)std::min<uint64_t>(512, std::max<uint64_t>(4, nsb * nt / 2 / 32768));
 }
 
 template <int LAW, int IPT>
@@ -514,10 +520,7 @@ int nb_allpairs_diag(nbody_ctx* ctx, const float4* posm_in, float4* diag_out, in
 // One part's share of the pair tiles of ALL bodies (PLUMMER): acc_tmp[j] for every j.
 int nb_allpairs_partial(nbody_ctx* ctx, uint32_t part, uint32_t nparts) {
     const int tpl = sym_tpl();
-    const uint64_t nsb = (ctx->n + 256 * tpl - 1) / (256 * tpl), nt = (ctx->n + 63) / 64;
-    uint32_t seg = (uint32_t)std::min<uint64_t>(512, std::max<uint64_t>(4, nsb * nt / 2 / 32768));
-    if (env_int("NBODY_AP_SEG", 0) > 0) seg = (uint32_t)env_int("NBODY_AP_SEG", 0);
-    return nb_allpairs_forces_sym(ctx, ctx->posm[ctx->cur], ctx->acc_tmp, seg, tpl, part, nparts);
+    return nb_allpairs_forces_sym(ctx, ctx->posm[ctx->cur], ctx->acc_tmp, sym_seg_tiles(ctx, tpl), tpl, part, nparts);
 }
 
 // Forces on this context's targets from all n sources in posm_in; acc_out[i] for i in the range.
@@ -530,10 +533,7 @@ int nb_allpairs_forces(nbody_ctx* ctx, const float4* posm_in, const float4* vel_
         ctx->n >= (sym_env == 1 ? 4097u : 65536u)) {
         // one evaluation per unordered pair; needs (superblocks x n / 2) x 16 B of partial rows
         const int tpl = sym_tpl();
-        // work items of `seg` source tiles each: aim at ~32K items (measured best at N = 1M)
-        const uint64_t nsb = (ctx->n + 256 * tpl - 1) / (256 * tpl), nt = (ctx->n + 63) / 64;
-        uint32_t seg = (uint32_t)std::min<uint64_t>(512, std::max<uint64_t>(4, nsb * nt / 2 / 32768));
-        if (env_int("NBODY_AP_SEG", 0) > 0) seg = (uint32_t)env_int("NBODY_AP_SEG", 0);
+        const uint32_t seg = sym_seg_tiles(ctx, tpl);
         size_t free_b = 0, total_b = 0;
         const uint64_t need = nb_sym_scratch_bytes(ctx->n, seg, 256u * tpl);
         const bool have = ctx->sym != nullptr;
@@ -598,44 +598,31 @@ static void launch_leapfrog(nbody_ctx* ctx, const float4* acc_new, float clamp_w
     ctx->leapfrog_started = true;
 }
 
-int nb_integrate(nbody_ctx* ctx, const float4* acc_new) {
+// clamp_world > 0: positions are clamped to [0, clamp_world] (src/nbodybh.wgsl:167).
+static int integrate(nbody_ctx* ctx, const float4* acc_new, float clamp_world) {
     unsigned fb = (unsigned)((ctx->i_count + 255) / 256);
     const int c = ctx->cur, o = ctx->cur ^ 1;
     if (ctx->cfg.integrator == NBODY_INT_CPU_EULER_XBUF) {
         hipLaunchKernelGGL(k_integrate_cpu_xbuf, dim3(fb), dim3(256), 0, ctx->stream, acc_new, ctx->posm[o], ctx->vel[o],
                            ctx->acc[o], (int)ctx->i_begin, (int)ctx->i_count);
     } else if (ctx->cfg.integrator == NBODY_INT_LEAPFROG) {
-        launch_leapfrog(ctx, acc_new, 0.0f);
+        launch_leapfrog(ctx, acc_new, clamp_world);
     } else {
         const float dt = ctx->cfg.dt;
         const float dt2 = std::pow(dt, 2.0f);  // pow(time_step, 2.0), src/nbody.wgsl:132
         hipLaunchKernelGGL(k_integrate_verlet, dim3(fb), dim3(256), 0, ctx->stream, ctx->posm[c], ctx->vel[c],
                            ctx->acc[c], acc_new, ctx->posm[o], ctx->vel[o], ctx->acc[o], (int)ctx->i_begin,
-                           (int)ctx->i_count, dt, dt2, 0.0f);
+                           (int)ctx->i_count, dt, dt2, clamp_world);
     }
     NB_HIP(ctx, hipGetLastError());
     ctx->cur = o;
     return NBODY_OK;
 }
 
-int nb_integrate_clamped(nbody_ctx* ctx, const float4* acc_new) {
-    unsigned fb = (unsigned)((ctx->i_count + 255) / 256);
-    const int c = ctx->cur, o = ctx->cur ^ 1;
-    if (ctx->cfg.integrator == NBODY_INT_LEAPFROG) {
-        launch_leapfrog(ctx, acc_new, ctx->cfg.world);
-        NB_HIP(ctx, hipGetLastError());
-        ctx->cur = o;
-        return NBODY_OK;
-    }
-    const float dt = ctx->cfg.dt;
-    const float dt2 = std::pow(dt, 2.0f);
-    hipLaunchKernelGGL(k_integrate_verlet, dim3(fb), dim3(256), 0, ctx->stream, ctx->posm[c], ctx->vel[c], ctx->acc[c],
-                       acc_new, ctx->posm[o], ctx->vel[o], ctx->acc[o], (int)ctx->i_begin, (int)ctx->i_count, dt, dt2,
-                       ctx->cfg.world);
-    NB_HIP(ctx, hipGetLastError());
-    ctx->cur = o;
-    return NBODY_OK;
-}
+int nb_integrate(nbody_ctx* ctx, const float4* acc_new) { return integrate(ctx, acc_new, 0.0f); }
+
+// The Barnes-Hut step; the caller has refused the cross-buffer integrator, which has no clamp.
+int nb_integrate_clamped(nbody_ctx* ctx, const float4* acc_new) { return integrate(ctx, acc_new, ctx->cfg.world); }
 
 int nb_energy(nbody_ctx* ctx, double* kinetic, double* potential) {
     if (!ctx->energy_dev) NB_HIP(ctx, hipMalloc(&ctx->energy_dev, 2 * sizeof(double)));

@@ -10,10 +10,10 @@
 // reactions on that source to the wavefront's own LDS accumulator by a plain read-add-write
 // (lane-distinct addresses, one wavefront per accumulator, LDS operations of a wavefront execute
 // in order; ds_add_f32 was measured an order of magnitude slower here).  After the tile the four
-// wavefronts' accumulators are summed in a fixed order and written as that item's partial row; a final kernel adds, per body
-// and in a fixed order, the partial rows of all earlier superblocks, the target-side partials of
-// its own superblock's items and the within-superblock term.  No atomics reach global memory, so
-// results are reproducible bit for bit.
+// wavefronts' accumulators are summed in a fixed order and written as that item's partial row; a
+// final kernel adds, per body and in a fixed order, the partial rows of all earlier superblocks,
+// the target-side partials of its own superblock's items and the within-superblock term.  No
+// atomics reach global memory, so results are reproducible bit for bit.
 //
 // Per step (P pair-interactions = 2 P ordered interactions) a lane issues 7 P v_pk_*_f32,
 // P v_rsq_f32 and 7 instructions that do not depend on P (the reaction's adds): about 18 cycles
@@ -85,11 +85,8 @@ __global__ __launch_bounds__(256) void k_ap_sym(const float4* __restrict__ posm,
         return s;
     };
     auto zero_acc = [&](int b) {
-#pragma unroll
-        for (int c = 0; c < 1; ++c) {
-            accj[b][wave][lane] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            accj[b][wave][lane + TILE] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        }
+        accj[b][wave][lane] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        accj[b][wave][lane + TILE] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     };
     auto flush = [&](uint32_t t, int b) {
         // one wavefront sums the four accumulators (fixed order) and writes the tile's partial row

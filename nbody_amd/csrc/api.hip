@@ -6,8 +6,6 @@
 
 thread_local std::string g_nbody_create_error;
 
-int nb_integrate_clamped(nbody_ctx* ctx, const float4* acc_new);
-
 namespace {
 
 __global__ void k_pack_posm(const float4* __restrict__ pos16, const float* __restrict__ masses, float4* __restrict__ posm,
@@ -189,8 +187,7 @@ void nbody_destroy(nbody_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
-    nb_time_collect(ctx, 0);
-    nb_time_collect(ctx, 1);
+    for (int which = 0; which < 3; ++which) nb_time_collect(ctx, which);
     nb_tree_destroy(ctx);
     nb_sym_destroy(ctx);
     for (int s = 0; s < 2; ++s) {
@@ -284,6 +281,8 @@ int nbody_step_bh(nbody_ctx* ctx, int nsteps) {
     if (nsteps < 0) return nb_fail(ctx, NBODY_ERR_INVALID, "nsteps < 0");
     if (ctx->cfg.law == NBODY_LAW_CPU_R6)
         return nb_fail(ctx, NBODY_ERR_INVALID, "the Barnes-Hut path uses the WGSL laws (src/nbodybh.wgsl), not CPU_R6");
+    if (ctx->cfg.integrator == NBODY_INT_CPU_EULER_XBUF)
+        return nb_fail(ctx, NBODY_ERR_INVALID, "the Barnes-Hut path integrates as src/nbodybh.wgsl:163-169 (or leapfrog), not with the cross-buffer Euler update");
     if (ctx->i_count < ctx->n && nsteps > 1)
         return nb_fail(ctx, NBODY_ERR_INVALID, "a sharded context steps once per call: all-gather NBODY_BUF_POSM between steps");
     int r = set_device(ctx);
@@ -305,6 +304,8 @@ int nbody_bh_forces_ranked(nbody_ctx* ctx, uint64_t rank_begin, uint64_t rank_co
     if (!ctx->uploaded) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_bh_forces_ranked: no bodies uploaded");
     if (ctx->cfg.law == NBODY_LAW_CPU_R6)
         return nb_fail(ctx, NBODY_ERR_INVALID, "the Barnes-Hut path uses the WGSL laws (src/nbodybh.wgsl), not CPU_R6");
+    if (ctx->cfg.integrator == NBODY_INT_CPU_EULER_XBUF)
+        return nb_fail(ctx, NBODY_ERR_INVALID, "the Barnes-Hut path integrates as src/nbodybh.wgsl:163-169 (or leapfrog), not with the cross-buffer Euler update");
     if (ctx->i_count != ctx->n)
         return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_bh_forces_ranked: the context must hold all bodies (no shard range)");
     if (rank_begin > ctx->n || rank_count > ctx->n - rank_begin)
@@ -321,6 +322,8 @@ int nbody_integrate_ranked(nbody_ctx* ctx) {
     if (!ctx->uploaded) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_integrate_ranked: no bodies uploaded");
     if (ctx->i_count != ctx->n)
         return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_integrate_ranked: the context must hold all bodies (no shard range)");
+    if (ctx->cfg.integrator == NBODY_INT_CPU_EULER_XBUF)
+        return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_integrate_ranked: the Barnes-Hut path integrates as src/nbodybh.wgsl:163-169 (or leapfrog), not with the cross-buffer Euler update");
     int r = set_device(ctx);
     if (r) return r;
     if (!ctx->acc_body) NB_HIP(ctx, hipMalloc(&ctx->acc_body, ctx->n * sizeof(float4)));

@@ -50,8 +50,6 @@ struct nbody_ctx {
     bool leapfrog_started = false;  // NBODY_INT_LEAPFROG: a step has been taken since the last upload
     // kernel timing (HIP events on `stream`)
     bool timing = false;
-    std::vector<hipEvent_t> ev_pool;  // pairs
-    size_t ev_used[2] = {0, 0};       // [0]=all-pairs, [1]=bh : number of recorded pairs
     std::vector<hipEvent_t> ev[3];  // 0 all-pairs force kernel, 1 traversal kernel, 2 octree build (all its launches)
     double time_acc_ms[3] = {0, 0, 0};
     uint64_t time_launches[3] = {0, 0, 0};

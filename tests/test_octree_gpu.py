@@ -314,6 +314,20 @@ def test_upload_rejects_bad_tree(orc):
             sim.accel_bh()          # no tree yet
 
 
+def test_step_bh_refuses_the_cpu_binary_configuration():
+    """src/nbodybh.wgsl has neither the r^-6 law nor the cross-buffer Euler update of
+    src/nbody_cpu.rs: asking for them is an error, not a silently different step."""
+    import nbody_amd as nb
+    m, pos = nb.gen_refcube(100, seed=1)
+    for cfg in (dict(law=nb.LAW_CPU_R6), dict(law=nb.LAW_WGSL_BIAS, integrator=nb.INT_CPU_EULER_XBUF)):
+        with nb.NBodySim(100, **cfg) as sim:
+            sim.upload(m, pos)
+            with pytest.raises(nb.NBodyError):
+                sim.step_bh(1)
+            with pytest.raises(nb.NBodyError):
+                sim.bh_forces_ranked(0, 100)
+
+
 def test_ranked_forces_and_integration_equal_a_plain_step(orc):
     """The replicated-state multi-GPU scheme on one context: traversal by runs of the sorted order
     into the rank-ordered buffer, then un-ranking + integration of all bodies == nbody_step_bh."""

@@ -741,7 +741,7 @@ __global__ __launch_bounds__(256) void k_compact_scatter(const uint32_t* __restr
 // children are fetched together when it is popped.
 constexpr bool WALK_PRECISE = false;  // one Newton step on v_rsq_f32 in the traversal's interactions
 constexpr int WALK_STACK = 160;  // >= 8 pushes per level x 17 levels + root
-constexpr int WALK_THREADS = 256;  // (one wavefront per workgroup was measured 5 % slower)
+constexpr int WALK_THREADS = 64;  // one wavefront per workgroup: its slot is refilled as soon as it ends (3 % over 256)
 constexpr int WALK_BATCH = 8;    // node records fetched together; the node array is padded by as many
 
 // The lanes for which p holds, as a wave-uniform value the compiler keeps in scalar registers
@@ -882,7 +882,9 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk(const QNode* __restrict__
                     if (qn_type(nd) == NBODY_NODE_LEAFBODY) n_leaf += __builtin_amdgcn_inverse_ballot_w64(take);
                     else n_agg += __builtin_amdgcn_inverse_ballot_w64(take);
                 }
-                if (take) {
+                // The cheap PLUMMER term is evaluated for every record: testing for "no lane takes
+                // it" costs more scalar instructions than the ten vector ones it sometimes saves.
+                if (QUAD || LAW != NBODY_LAW_PLUMMER ? take != 0 : true) {
                     // every lane evaluates the term; lanes that do not take it add zero
                     float ri = 0.0f;  // QUAD (PLUMMER law only): 1/R shared by the monopole and quadrupole terms
                     float sc;

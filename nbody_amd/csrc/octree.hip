@@ -45,7 +45,8 @@ constexpr uint32_t NO_NODE = 0xffffffffu;
 // as two thresholds on the squared distance: r^2 > r2_accept settles "accept", r^2 < r2_open
 // settles "open"; in the narrow band between them (relative width 8e-6) the traversal evaluates
 // the reference's expression itself, with the node's range from a side array.  A LEAFBODY record
-// has both thresholds below zero (QN_ALWAYS).
+// has both thresholds below zero (QN_ALWAYS).  (Under the PLUMMER law both sides of these
+// compares carry the softening eps2, see MacScale.)
 struct QNode {
     float cx, cy, cz, mass;
     float r2_open, r2_accept;
@@ -60,14 +61,19 @@ __host__ __device__ __forceinline__ uint32_t qn_pack(uint32_t count, uint32_t ty
 // record as a source for every lane without looking at its type.
 constexpr float QN_ALWAYS = -1.0f;
 
-// 1 / (theta^2 (1 +- 4e-6)): the squared-distance thresholds of a node are range^2 times these.
+// The squared-distance thresholds of a node are range^2 * {open, accept} + {soft_open, soft_accept}:
+// open, accept = 1 / (theta^2 (1 +- 4e-6)).  Under the PLUMMER law the traversal compares the
+// SOFTENED squared distance r^2 + eps2 (the only form of it the force term needs), so the
+// thresholds carry eps2 (1 -+ 1e-6) as well; the margins cover the f32 rounding of both sides
+// (1.8e-7 of r^2 + eps2 for the sum, 5e-7 of r^2 for the reference's own sqrt and division).
 struct MacScale {
     float open, accept;
+    float soft_open, soft_accept;
 };
 __device__ __forceinline__ void qn_set_range(QNode& nd, float range, MacScale mac) {
     const float q = range * range;
-    nd.r2_open = q * mac.open;
-    nd.r2_accept = q * mac.accept;
+    nd.r2_open = q * mac.open + mac.soft_open;
+    nd.r2_accept = q * mac.accept + mac.soft_accept;
 }
 static_assert(sizeof(QNode) == 32, "node record layout");
 
@@ -853,7 +859,9 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk(const QNode* __restrict__
                     n_visit += __builtin_amdgcn_inverse_ballot_w64(mask);
                 }
                 const float dx = nd.cx - t.x, dy = nd.cy - t.y, dz = nd.cz - t.z;
-                const float r2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+                // PLUMMER: the softened squared distance, which the thresholds are prepared for
+                const float r2 = LAW == NBODY_LAW_PLUMMER ? fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, eps2)))
+                                                          : fmaf(dx, dx, fmaf(dy, dy, dz * dz));
                 // Lanes that take this node as one source.  src/nbodybh.wgsl:104-106 by the node's
                 // squared-distance thresholds; a LEAFBODY record (a direct interaction,
                 // src/nbodybh.wgsl:76-102) carries thresholds below zero, which every lane passes.
@@ -888,8 +896,8 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk(const QNode* __restrict__
                     // every lane evaluates the term; lanes that do not take it add zero
                     float ri = 0.0f;  // QUAD (PLUMMER law only): 1/R shared by the monopole and quadrupole terms
                     float sc;
-                    if (QUAD) {
-                        ri = __builtin_amdgcn_rsqf(r2 + eps2);
+                    if (LAW == NBODY_LAW_PLUMMER) {  // src/nbody.wgsl:56-65; r2 is softened already
+                        ri = WALK_PRECISE ? rsq_refined(r2) : __builtin_amdgcn_rsqf(r2);
                         sc = (nd.mass * ri) * (ri * ri);
                     } else {
                         sc = pair_scale<LAW, WALK_PRECISE>(t, dx, dy, dz, r2, nd.mass, eps2);
@@ -933,7 +941,8 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk(const QNode* __restrict__
 // them and the reference's expression, evaluated in the band, opens every node as it should.
 MacScale mac_scale(const nbody_ctx* ctx) {
     const float th2 = ctx->cfg.theta * ctx->cfg.theta;
-    return MacScale{1.0f / (th2 * (1.0f + 4e-6f)), 1.0f / (th2 * (1.0f - 4e-6f))};
+    const float soft = ctx->cfg.law == NBODY_LAW_PLUMMER ? ctx->cfg.eps2 : 0.0f;
+    return MacScale{1.0f / (th2 * (1.0f + 4e-6f)), 1.0f / (th2 * (1.0f - 4e-6f)), soft * (1.0f - 1e-6f), soft * (1.0f + 1e-6f)};
 }
 
 int ensure_nodes(nbody_ctx* ctx, Octree* T, uint64_t need) {

@@ -73,6 +73,9 @@ def main():
                     help="body count (use --bodies under torch.distributed.run, whose own parser claims --n)")
     ap.add_argument("--law", default="plummer", choices=["plummer", "wgsl_bias"])
     ap.add_argument("--no-extras", action="store_true", help="skip the WGSL-law, Barnes-Hut and CPU-baseline legs")
+    ap.add_argument("--bh-balance-every", type=int, default=0,
+                    help="Barnes-Hut legs on several GPUs: every K steps move the ranks' runs of the sorted order after "
+                         "their measured traversal times (0: equal runs; a centred Plummer sphere is balanced as it is)")
     ap.add_argument("--config2", action="store_true",
                     help="add all-pairs legs at N=65536 (they launch the headline kernel too, which would blur its "
                          "average in a profile of this command, so they are off by default)")
@@ -222,10 +225,10 @@ def main():
         b_, c_ = shard_range(nbodies, rank, world)
         be = HipShardBackend(nbodies, b_, c_, local_rank, law=nb.LAW_PLUMMER if bh_law is None else bh_law, bh_ranked=True)
         be.upload(m_, p_, v_)
-        sim = ShardedSim(be, nbodies, rank, world)
+        sim = ShardedSim(be, nbodies, rank, world, bh_balance_every=args.bh_balance_every)
         sim.step_bh(2)
         be.sim.set_counting(True)
-        be.sim.bh_forces_ranked(b_, c_)   # counting build of the traversal kernel, own targets only
+        be.sim.bh_forces_ranked(*sim.bh_ranges[rank])   # counting build of the traversal kernel, own targets only
         c = be.sim.counters()
         be.sim.set_counting(False)
         be.sim.set_kernel_timing(True)

@@ -30,6 +30,32 @@ import torch
 import torch.distributed as dist
 
 
+def balance_ranges(ranges, costs, n, quantum=64):
+    """Contiguous ranges of equal estimated cost.  `costs[r]` is what rank r measured for its
+    current range `ranges[r] = (begin, count)`; within a range the cost is taken as evenly spread.
+    Boundaries are rounded to `quantum` (64 keeps every wavefront's 64 targets together, so the
+    traversal results do not depend on where the boundaries fall)."""
+    world = len(ranges)
+    total = float(sum(costs))
+    segs = [(b, c, float(t)) for (b, c), t in zip(ranges, costs) if c > 0 and t > 0]
+    if total <= 0 or not segs:
+        return [shard_range(n, r, world) for r in range(world)]
+    total = sum(t for _, _, t in segs)
+    bounds = [0]
+    for r in range(1, world):
+        target = total * r / world
+        acc, x = 0.0, float(n)
+        for b, c, t in segs:
+            if acc + t >= target:
+                x = b + (target - acc) / t * c
+                break
+            acc += t
+        xi = int(round(x / quantum)) * quantum
+        bounds.append(min(max(xi, bounds[-1]), n))
+    bounds.append(n)
+    return [(bounds[r], bounds[r + 1] - bounds[r]) for r in range(world)]
+
+
 def shard_range(n, rank, world):
     """Contiguous near-equal split: the first n % world ranks get one body more."""
     base, extra = divmod(n, world)
@@ -70,6 +96,7 @@ class HipShardBackend:
         self.sim = NBodySim(n, device=device_index, stream=self.torch_stream.cuda_stream, **cfg)
         self.n = n
         self._views = {}
+        self._timing = False
 
     def upload(self, masses, pos16, vel16=None):
         self.sim.upload(masses, pos16, vel16)
@@ -95,8 +122,16 @@ class HipShardBackend:
     def integrate_partial(self):
         self.sim.integrate_partial()
 
-    def bh_forces_ranked(self):
-        self.sim.bh_forces_ranked(self.begin, self.count)
+    def bh_forces_ranked(self, begin=None, count=None):
+        self.sim.bh_forces_ranked(self.begin if begin is None else begin, self.count if count is None else count)
+
+    def bh_cost(self):
+        """Average traversal-kernel time (ms) of this rank since the last call; blocks on the stream."""
+        if not self._timing:
+            self.sim.set_kernel_timing(True)
+            self._timing = True
+            return 0.0
+        return self.sim.kernel_time(bh=True)[0]
 
     def integrate_ranked(self):
         self.sim.integrate_ranked()
@@ -109,7 +144,11 @@ class HipShardBackend:
 
 
 class ShardedSim:
-    def __init__(self, backend, n, rank=None, world=None, group=None):
+    def __init__(self, backend, n, rank=None, world=None, group=None, bh_balance_every=0):
+        """bh_balance_every = K > 0 (replicated-state Barnes-Hut only): every K steps the ranks
+        exchange their measured traversal times and move the boundaries of their runs of the
+        sorted order so that the times even out (for bodies that are not spread symmetrically
+        over the Morton order; a centred Plummer sphere is balanced within 2 % as it is)."""
         self.backend = backend
         self.n = n
         self.group = group
@@ -117,6 +156,11 @@ class ShardedSim:
         self.world = dist.get_world_size(group) if world is None else world
         self.begin, self.count = shard_range(n, self.rank, self.world)
         self._nccl = dist.get_backend(group) == "nccl" if dist.is_initialized() else False
+        self.ranges = [shard_range(n, r, self.world) for r in range(self.world)]
+        self.bh_ranges = list(self.ranges)       # runs of the sorted order, one per rank
+        self.bh_balance_every = bh_balance_every
+        self._bh_steps = 0
+        self._stage = None
 
     def _stream(self):
         """Collectives and tensor ops must be enqueued on the stream the backend computes on."""
@@ -131,32 +175,38 @@ class ShardedSim:
             self._exchange()
 
     def _exchange(self):
-        self._gather_ranges(self.backend.posm())
+        self._gather_ranges(self.backend.posm(), self.ranges)
 
-    def _gather_ranges(self, full):
-        """full[begin_r : begin_r + count_r] of every rank r reaches all ranks (in place)."""
-        if self.n % self.world == 0:
-            # a private copy of the own range (16 B/body): input and output never alias
-            own = full[self.begin:self.begin + self.count].clone()
-            if full.is_cuda and not self._nccl:
-                # device tensors over a host-only backend (tests: gloo): stage through the host
-                host = torch.empty(full.shape, dtype=full.dtype)
-                dist.all_gather_into_tensor(host, own.cpu(), group=self.group)
-                full.copy_(host)
-            else:
-                dist.all_gather_into_tensor(full, own, group=self.group)
+    def _all_gather(self, out, own):
+        """all_gather_into_tensor; device tensors over a host-only backend (tests: gloo) are staged
+        through the host."""
+        if out.is_cuda and not self._nccl:
+            host = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(host, own.cpu(), group=self.group)
+            out.copy_(host)
         else:
-            for r in range(self.world):
-                b, c = shard_range(self.n, r, self.world)
-                src = dist.get_global_rank(self.group, r) if self.group else r
-                part = full[b:b + c]
-                if full.is_cuda and not self._nccl:
-                    host = part.cpu()
-                    dist.broadcast(host, src=src, group=self.group)
-                    if r != self.rank:
-                        part.copy_(host)
-                else:
-                    dist.broadcast(part, src=src, group=self.group)
+            dist.all_gather_into_tensor(out, own, group=self.group)
+
+    def _gather_ranges(self, full, ranges):
+        """full[begin_r : begin_r + count_r] of every rank r reaches all ranks (in place).  One
+        equal-sized all-gather in every case: ranks with unequal counts contribute a window of
+        max(count) rows that contains their range."""
+        counts = [c for _, c in ranges]
+        b, c = ranges[self.rank]
+        if min(counts) == max(counts):
+            # a private copy of the own range (16 B/body): input and output never alias
+            self._all_gather(full, full[b:b + c].clone())
+            return
+        cmax = max(counts)
+        window = lambda br: min(br, self.n - cmax)       # start of the cmax-row window of a range
+        if self._stage is None or self._stage.shape[0] != self.world * cmax or self._stage.device != full.device:
+            self._stage = torch.empty((self.world * cmax,) + tuple(full.shape[1:]), dtype=full.dtype, device=full.device)
+        self._all_gather(self._stage, full[window(b):window(b) + cmax])
+        for r, (br, cr) in enumerate(ranges):
+            if r == self.rank or cr == 0:
+                continue
+            off = r * cmax + (br - window(br))
+            full[br:br + cr].copy_(self._stage[off:off + cr])
 
     def _sum_partials(self):
         part = self.backend.acc_partial()
@@ -186,10 +236,25 @@ class ShardedSim:
         ranked = getattr(self.backend, "bh_ranked", False)
         for _ in range(nsteps):
             if ranked and self.world > 1:
-                self.backend.bh_forces_ranked()
+                if self.bh_balance_every and self._bh_steps % self.bh_balance_every == 0:
+                    self._rebalance_bh()
+                self.backend.bh_forces_ranked(*self.bh_ranges[self.rank])
                 with self._stream():
-                    self._gather_ranges(self.backend.acc_partial())
+                    self._gather_ranges(self.backend.acc_partial(), self.bh_ranges)
                 self.backend.integrate_ranked()
+                self._bh_steps += 1
             else:
                 self.backend.step("bh")
                 self.exchange()
+
+    def _rebalance_bh(self):
+        """Every rank learns every rank's traversal time and derives the same new boundaries."""
+        cost = float(self.backend.bh_cost())
+        dev = "cuda" if (self._nccl and torch.cuda.is_available()) else "cpu"
+        with self._stream() if dev == "cuda" else contextlib.nullcontext():
+            mine = torch.tensor([cost], dtype=torch.float64, device=dev)
+            every = torch.empty(self.world, dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(every, mine, group=self.group)
+            costs = every.cpu().tolist()
+        if min(costs) > 0:       # (the first call only switches the measurement on)
+            self.bh_ranges = balance_ranges(self.bh_ranges, costs, self.n)

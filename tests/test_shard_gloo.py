@@ -69,7 +69,9 @@ class OracleShardBackend:
 
     # replicated-state Barnes-Hut: accelerations of the bodies at sorted ranks [b, b + c) into
     # partial[rank]; after the all-gather every rank integrates ALL bodies
-    def bh_forces_ranked(self):
+    def bh_forces_ranked(self, begin=None, count=None):
+        if begin is not None:
+            self.b, self.c = begin, count
         orc = self.orc
         f = self.full.numpy()
         pos = np.zeros((self.n, 4), np.float32)
@@ -79,6 +81,12 @@ class OracleShardBackend:
         a, _ = orc.bh_accel(self.law, pos, self.vel, nodes)
         own = slice(self.b, self.b + self.c)
         self.partial.numpy()[own] = a[self.order[own]]
+
+    def bh_cost(self):
+        """A made-up cost for the balancing test: ranks in the first half of the sorted order are
+        three times as expensive as the rest."""
+        r = np.arange(self.b, self.b + self.c)
+        return float(np.where(r < self.n // 2, 3.0, 1.0).sum())
 
     def integrate_ranked(self):
         orc = self.orc
@@ -115,7 +123,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, law, kind, steps, out_dir, pair=False, ranked=False):
+def _worker(rank, world, port, n, law, kind, steps, out_dir, pair=False, ranked=False, balance=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, ROOT)
@@ -131,18 +139,19 @@ def _worker(rank, world, port, n, law, kind, steps, out_dir, pair=False, ranked=
         b, c = shard_range(n, rank, world)
         be = OracleShardBackend(n, b, c, law, pair_sharding=pair, bh_ranked=ranked)
         be.upload(m, pos, vel)
-        sim = ShardedSim(be, n)
+        sim = ShardedSim(be, n, bh_balance_every=balance)
         assert (sim.begin, sim.count) == (b, c)
         (sim.step_bh if kind == "bh" else sim.step_allpairs)(steps)
         np.save(os.path.join(out_dir, f"posm_{rank}.npy"), be.full.numpy())
         np.save(os.path.join(out_dir, f"vel_{rank}.npy"), be.vel[b:b + c])
+        np.save(os.path.join(out_dir, f"ranges_{rank}.npy"), np.array(sim.bh_ranges))
     finally:
         dist.destroy_process_group()
 
 
-def _run(world, n, law, kind, steps, tmp_path, pair=False, ranked=False):
+def _run(world, n, law, kind, steps, tmp_path, pair=False, ranked=False, balance=0):
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, n, law, kind, steps, str(tmp_path), pair, ranked), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, n, law, kind, steps, str(tmp_path), pair, ranked, balance), nprocs=world, join=True)
     from nbody_amd.shard import shard_range
     full = [np.load(tmp_path / f"posm_{r}.npy") for r in range(world)]
     vel = np.zeros((n, 4), np.float32)
@@ -200,6 +209,46 @@ def test_ranked_bh_equals_unsharded(orc, tmp_path, world, n):
     for f in full:
         assert np.array_equal(f[:, :3], rp[:, :3])
     assert np.array_equal(vel, rv)      # assembled from each rank's own slice of its replicated copy
+
+
+def test_balance_ranges():
+    from nbody_amd.shard import balance_ranges, shard_range
+    n = 1 << 20
+    eq = [shard_range(n, r, 4) for r in range(4)]
+    assert balance_ranges(eq, [1.0, 1.0, 1.0, 1.0], n) == eq
+    assert balance_ranges(eq, [0.0, 0.0, 0.0, 0.0], n) == eq            # nothing measured yet
+    got = balance_ranges(eq, [2.0, 2.0, 1.0, 1.0], n)
+    assert got == [(0, 196608), (196608, 196608), (393216, 262144), (655360, 393216)]
+    for ranges, costs, total in ((eq, [5.0, 0.1, 0.1, 7.0], n), ([(0, 100), (100, 0), (100, 200)], [1.0, 0.0, 4.0], 300)):
+        new = balance_ranges(ranges, costs, total, quantum=1 if total == 300 else 64)
+        assert new[0][0] == 0 and sum(c for _, c in new) == total
+        for (b0, c0), (b1, _) in zip(new, new[1:]):
+            assert b0 + c0 == b1 and c0 >= 0
+    # a second round on the re-measured costs of a piecewise-constant density leaves the boundaries alone
+    dens = lambda b, c: 2.0 * max(0, min(b + c, n // 2) - b) + 1.0 * max(0, b + c - max(b, n // 2))
+    r1 = balance_ranges(eq, [dens(b, c) for b, c in eq], n)
+    r2 = balance_ranges(r1, [dens(b, c) for b, c in r1], n)
+    assert r1 == r2 and abs(dens(*r1[0]) - dens(*r1[3])) <= 2 * 64
+
+
+def test_ranked_bh_with_rebalancing_equals_unsharded(orc, tmp_path):
+    """Boundaries that move between steps (uneven runs, the padded all-gather) change nothing in
+    the result; all ranks derive the same boundaries."""
+    world, n, steps, law = 3, 700, 3, orc.LAW_PLUMMER
+    full, vel = _run(world, n, law, "bh", steps, tmp_path, ranked=True, balance=1)
+    m, pos = orc.gen_refcube(n, seed=8)
+    v0 = np.zeros((n, 4), np.float32)
+    v0[:, :3] = 0.2 * (orc.gen_refcube(n, seed=9)[1][:, :3] / 125.0 - 1.0)
+    rp, rv, ra = orc.step_bh(law, m, pos, v0, np.zeros_like(pos), steps)
+    for f in full:
+        assert np.array_equal(f[:, :3], rp[:, :3])
+    ranges = [np.load(tmp_path / f"ranges_{r}.npy") for r in range(world)]
+    assert all(np.array_equal(ranges[0], x) for x in ranges)
+    from nbody_amd.shard import shard_range
+    assert ranges[0].tolist() != [list(shard_range(n, r, world)) for r in range(world)]     # they did move
+    assert ranges[0][:, 1].sum() == n and (ranges[0][1:, 0] % 64 == 0).all()
+    # the expensive half got the shorter runs
+    assert ranges[0][0, 1] < ranges[0][2, 1]
 
 
 def test_pair_sharded_allpairs_matches_unsharded(orc, tmp_path):

@@ -34,15 +34,15 @@ os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[4])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 note("process group up")
 
-def run(n, law, kind, steps, dataset, ranked=False):
+def run(n, law, kind, steps, dataset, ranked=False, balance=0):
     import time
     t0 = time.time()
     try:
-        return run_(n, law, kind, steps, dataset, ranked)
+        return run_(n, law, kind, steps, dataset, ranked, balance)
     finally:
         note("case", n, law, kind, f"{time.time() - t0:.1f} s")
 
-def run_(n, law, kind, steps, dataset, ranked):
+def run_(n, law, kind, steps, dataset, ranked, balance):
     m, pos, vel = dataset(n)
     ref = nb.NBodySim(n, law=law)
     ref.upload(m, pos, vel)
@@ -52,9 +52,14 @@ def run_(n, law, kind, steps, dataset, ranked):
     b, c = shard_range(n, rank, world)
     be = HipShardBackend(n, b, c, 0, law=law, bh_ranked=ranked)
     be.upload(m, pos, vel)
-    sim = ShardedSim(be, n, rank, world)
+    sim = ShardedSim(be, n, rank, world, bh_balance_every=balance)
     (sim.step_bh if kind == "bh" else sim.step_allpairs)(steps)
     torch.cuda.synchronize()
+    if balance:
+        # measured traversal times moved the boundaries (or left them); they still tile the order
+        r = sim.bh_ranges
+        assert r[0][0] == 0 and sum(c for _, c in r) == n and all(b % 64 == 0 for b, _ in r), r
+        note("balanced ranges", r)
     p, v, a = be.download()
     pair = be.pair_sharding and kind != "bh"
     be.sim.close()
@@ -77,13 +82,14 @@ plummer = lambda n: nb.gen_plummer(n, seed=5)
 def refcube(n):
     m, p = nb.gen_refcube(n, seed=5)
     return m, p, None
-assert not run(4097, nb.LAW_WGSL_BIAS, "allpairs", 3, refcube)     # ragged split, broadcast exchange
+assert not run(4097, nb.LAW_WGSL_BIAS, "allpairs", 3, refcube)     # ragged split: unequal counts, windowed all-gather
 assert not run(8192, nb.LAW_PLUMMER, "allpairs", 3, plummer)       # below the pair-sharding size
 assert run(65536, nb.LAW_PLUMMER, "allpairs", 2, plummer)          # pair tiles dealt over the ranks
 assert not run(20000, nb.LAW_WGSL_BIAS, "bh", 3, refcube)          # replicated tree, sharded walk
 assert not run(30001, nb.LAW_PLUMMER, "bh", 3, plummer)
 assert not run(20000, nb.LAW_WGSL_BIAS, "bh", 3, refcube, ranked=True)   # replicated state, traversal split by sorted rank
 assert not run(30001, nb.LAW_PLUMMER, "bh", 3, plummer, ranked=True)
+assert not run(30001, nb.LAW_PLUMMER, "bh", 7, plummer, ranked=True, balance=2)   # boundaries follow the measured times
 dist.barrier()
 dist.destroy_process_group()
 print("RANK_OK", rank)

@@ -537,21 +537,36 @@ __global__ void k_aggregate(QNode* __restrict__ nodes, float4* __restrict__ bmin
     QNode nd = nodes[id];
     if (qn_type(nd) != NBODY_NODE_INTERIOR) return;
     const uint32_t c0 = nd.first, c1 = (r + 1 < count) ? nodes[id + 1].first : child_end;
+    // An interior node has at most eight children: all their records (and the boxes of those that
+    // are cells themselves) are requested before the first is used; the sums then run in child
+    // order, as a loop over the children would.
+    QNode ch[8];
+    float4 lo[8], hi[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (c0 + k < c1) ch[k] = nodes[c0 + k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (c0 + k < c1) {
+            lo[k] = hi[k] = make_float4(ch[k].cx, ch[k].cy, ch[k].cz, 0.0f);
+            if (qn_type(ch[k]) != NBODY_NODE_LEAFBODY) {
+                lo[k] = bmin[c0 + k];
+                hi[k] = bmax[c0 + k];
+            }
+        }
+    }
     float M = 0.0f, wx = 0.0f, wy = 0.0f, wz = 0.0f;
     float mnx = INFINITY, mny = INFINITY, mnz = INFINITY, mxx = -INFINITY, mxy = -INFINITY, mxz = -INFINITY;
-    for (uint32_t c = c0; c < c1; ++c) {
-        const QNode ch = nodes[c];
-        M += ch.mass;
-        wx += ch.cx * ch.mass;
-        wy += ch.cy * ch.mass;
-        wz += ch.cz * ch.mass;
-        float4 lo = make_float4(ch.cx, ch.cy, ch.cz, 0.0f), hi = lo;
-        if (qn_type(ch) != NBODY_NODE_LEAFBODY) {
-            lo = bmin[c];
-            hi = bmax[c];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (c0 + k < c1) {
+            M += ch[k].mass;
+            wx += ch[k].cx * ch[k].mass;
+            wy += ch[k].cy * ch[k].mass;
+            wz += ch[k].cz * ch[k].mass;
+            mnx = fminf(mnx, lo[k].x); mny = fminf(mny, lo[k].y); mnz = fminf(mnz, lo[k].z);
+            mxx = fmaxf(mxx, hi[k].x); mxy = fmaxf(mxy, hi[k].y); mxz = fmaxf(mxz, hi[k].z);
         }
-        mnx = fminf(mnx, lo.x); mny = fminf(mny, lo.y); mnz = fminf(mnz, lo.z);
-        mxx = fmaxf(mxx, hi.x); mxy = fmaxf(mxy, hi.y); mxz = fmaxf(mxz, hi.z);
     }
     nd.mass = M;
     nd.cx = wx / M;

@@ -248,6 +248,39 @@ def test_walk_matches_reference_walk_on_identical_tree(orc, name, law):
     assert np.quantile(err, 0.99) < 1e-4 and err.max() < 2e-2
 
 
+@pytest.mark.parametrize("law", [1, 2])
+@pytest.mark.parametrize("theta,eps2", [(0.3, 1.0), (1.0, 1.0), (0.5, 1e-6), (0.5, 1e-4), (0.5, 100.0), (0.8, 0.01)])
+def test_walk_decisions_for_other_opening_angles_and_softenings(orc, law, theta, eps2):
+    """The per-node acceptance thresholds are prepared from theta (and, under the PLUMMER law,
+    carry the softening): the decisions must stay the reference's for any of them, seen as equal
+    visit / interaction counts on the same tree bytes, and accelerations within tolerance."""
+    import nbody_amd as nb
+    m, pos = dataset(orc, "clustered" if eps2 < 1.0 else "plummer20000")
+    n = len(m)
+    vel = np.zeros((n, 4), np.float32)
+    vel[:, :3] = 0.4 * (orc.gen_refcube(n, seed=78)[1][:, :3] / 125.0 - 1.0)
+    with nb.NBodySim(n, law=law, theta=theta, eps2=eps2) as sim:
+        sim.upload(m, pos, vel)
+        sim.build_octree()
+        nodes = sim.download_octree().view(orc.NODE_DTYPE)
+        sim.set_counting(True)
+        acc = sim.accel_bh()
+        c = sim.counters()
+        sim.set_counting(False)
+        fast = sim.accel_bh()            # the non-counting build of the kernel: same bits
+    ref, cnt = orc.bh_accel(law, pos, vel, nodes, eps2=eps2, theta=theta)
+    assert (c["bh_node_visits"], c["bh_leaf_interactions"], c["bh_aggregate_interactions"]) == \
+        (cnt["visits"], cnt["leaf"], cnt["aggregate"])
+    assert np.array_equal(acc, fast)
+    ref64 = orc.bh_accel_f64(law, pos, vel, nodes, eps2=eps2, theta=theta)
+    e_gpu = np.linalg.norm(acc[:, :3].astype(np.float64) - ref64, axis=1)
+    e_ref = np.linalg.norm(ref[:, :3].astype(np.float64) - ref64, axis=1)
+    scale = np.linalg.norm(ref64, axis=1)
+    # unsoftened close pairs amplify the f32 rounding of the separation itself: both sides are
+    # held to the same bound relative to the f64 evaluation of the same node sequence
+    assert (e_gpu <= 1e-5 * scale + 4 * e_ref + 1e-30).all(), float(np.max(e_gpu / scale))
+
+
 def test_theta_zero_walk_equals_allpairs(orc):
     import nbody_amd as nb
     m, pos = orc.gen_refcube(1500, seed=12)

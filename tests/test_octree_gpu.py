@@ -195,6 +195,25 @@ def test_shallow_depth_caps_make_leaf_lists(orc, max_depth):
         assert np.array_equal(keys, orc.morton_keys(pos, levels=max_depth))
 
 
+@pytest.mark.parametrize("world", [64.0, 1000.0, 3.0])
+def test_other_world_sizes(orc, world):
+    """The root cell is configuration (src/octree_maxdepth.rs:28-29 has 250): keys, leaves and
+    the tree for other extents, including one that is not a power of two times anything."""
+    import nbody_amd as nb
+    m, pos = orc.gen_refcube(3000, seed=21)
+    pos = pos.copy()
+    pos[:, :3] = (pos[:, :3] * np.float32(world / 250.0)).astype(np.float32)
+    with nb.NBodySim(len(m), world=world) as sim:
+        sim.upload(m, pos)
+        sim.build_octree()
+        keys, depth, _ = sim.morton_keys()
+        nodes = sim.download_octree()
+    assert np.array_equal(keys, orc.morton_keys(pos, world=world))
+    ref_nodes, _, dep, _ = orc.build_octree(pos, m, world=world)
+    assert np.array_equal(depth, dep)
+    compare_trees(nodes, ref_nodes, pos, m, keys, depth)
+
+
 def test_tiny_trees(orc):
     import nbody_amd as nb
     for rows in ([[10, 10, 10]], [[10, 10, 10], [200, 200, 200]], [[1, 1, 1], [20, 20, 20]],

@@ -214,6 +214,28 @@ def test_other_world_sizes(orc, world):
     compare_trees(nodes, ref_nodes, pos, m, keys, depth)
 
 
+def test_bodies_outside_the_root_cell(orc):
+    """The all-pairs step does not clamp (src/nbody.wgsl:132-138), so a tree may be asked for
+    bodies outside [0, world]^3: the reference's descent only compares with cell centres, and
+    such bodies end up in the outermost cells; same keys, same tree."""
+    import nbody_amd as nb
+    m, pos = orc.gen_refcube(2000, seed=33)
+    pos = pos.copy()
+    pos[:, :3] = (pos[:, :3] - 125.0) * np.float32(2.4) + 125.0        # [-55, 305]
+    assert (pos[:, :3] < 0).any() and (pos[:, :3] > 250).any()
+    with nb.NBodySim(len(m)) as sim:
+        sim.upload(m, pos)
+        sim.build_octree()
+        keys, depth, _ = sim.morton_keys()
+        nodes = sim.download_octree()
+        acc = sim.accel_bh()
+    assert np.array_equal(keys, orc.morton_keys(pos))
+    ref_nodes, _, dep, _ = orc.build_octree(pos, m)
+    assert np.array_equal(depth, dep)
+    compare_trees(nodes, ref_nodes, pos, m, keys, depth)
+    check_walk(orc, 1, pos, np.zeros_like(pos), nodes.view(orc.NODE_DTYPE), acc, "bodies outside the root cell")
+
+
 def test_tiny_trees(orc):
     import nbody_amd as nb
     for rows in ([[10, 10, 10]], [[10, 10, 10], [200, 200, 200]], [[1, 1, 1], [20, 20, 20]],

@@ -23,6 +23,19 @@ __global__ void k_strip_pad(const float4* __restrict__ posm, float4* __restrict_
     pos16[i] = make_float4(p.x, p.y, p.z, 0.0f);
 }
 
+// Host-side allocations (std::vector, std::string, new) inside the library must not let an
+// exception cross the C boundary.
+template <class F>
+int guarded(nbody_ctx* ctx, F&& body) {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return nb_fail(ctx, NBODY_ERR_NOMEM, "out of host memory");
+    } catch (...) {
+        return nb_fail(ctx, NBODY_ERR_HIP, "unexpected exception inside the library");
+    }
+}
+
 int set_device(nbody_ctx* ctx) {
     NB_HIP(ctx, hipSetDevice(ctx->device));
     return NBODY_OK;
@@ -177,7 +190,8 @@ int nbody_create(nbody_ctx** out, const nbody_config* cfg) {
         hipMemsetAsync(ctx->acc[s], 0, b16, ctx->stream);
     }
     hipMemsetAsync(ctx->masses, 0, ctx->n * sizeof(float), ctx->stream);
-    if (nb_tree_create(ctx) != NBODY_OK) return fail(NBODY_ERR_NOMEM, "octree workspace: " + ctx->err);
+    if (guarded(ctx, [&]() -> int { return nb_tree_create(ctx); }) != NBODY_OK)
+        return fail(NBODY_ERR_NOMEM, "octree workspace: " + ctx->err);
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(NBODY_ERR_HIP, "stream sync failed");
     *out = ctx;
     return NBODY_OK;
@@ -242,14 +256,16 @@ int nbody_step_allpairs(nbody_ctx* ctx, int nsteps) {
         return nb_fail(ctx, NBODY_ERR_INVALID, "a sharded context steps once per call: all-gather NBODY_BUF_POSM between steps");
     int r = set_device(ctx);
     if (r) return r;
-    for (int s = 0; s < nsteps; ++s) {
-        r = nb_allpairs_forces(ctx, ctx->posm[ctx->cur], ctx->vel[ctx->cur], ctx->acc_tmp);
-        if (r) return r;
-        r = nb_integrate(ctx, ctx->acc_tmp);
-        if (r) return r;
-        ctx->counters.steps_allpairs += 1;
-    }
-    return NBODY_OK;
+    return guarded(ctx, [&]() -> int {
+        for (int s = 0; s < nsteps; ++s) {
+            int rc = nb_allpairs_forces(ctx, ctx->posm[ctx->cur], ctx->vel[ctx->cur], ctx->acc_tmp);
+            if (rc) return rc;
+            rc = nb_integrate(ctx, ctx->acc_tmp);
+            if (rc) return rc;
+            ctx->counters.steps_allpairs += 1;
+        }
+        return NBODY_OK;
+    });
 }
 
 int nbody_allpairs_partial(nbody_ctx* ctx, uint32_t part, uint32_t nparts) {
@@ -261,7 +277,7 @@ int nbody_allpairs_partial(nbody_ctx* ctx, uint32_t part, uint32_t nparts) {
     if (ctx->n < 4097) return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_allpairs_partial: needs at least two superblocks of bodies (N > 4096)");
     int r = set_device(ctx);
     if (r) return r;
-    return nb_allpairs_partial(ctx, part, nparts);
+    return guarded(ctx, [&]() -> int { return nb_allpairs_partial(ctx, part, nparts); });
 }
 
 int nbody_integrate_partial(nbody_ctx* ctx) {
@@ -340,7 +356,7 @@ int nbody_accel_allpairs(nbody_ctx* ctx, float* host_acc16_out) {
     if (!ctx->uploaded) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_accel_allpairs: no bodies uploaded");
     int r = set_device(ctx);
     if (r) return r;
-    r = nb_allpairs_forces(ctx, ctx->posm[ctx->cur], ctx->vel[ctx->cur], ctx->acc_tmp);
+    r = guarded(ctx, [&]() -> int { return nb_allpairs_forces(ctx, ctx->posm[ctx->cur], ctx->vel[ctx->cur], ctx->acc_tmp); });
     if (r) return r;
     NB_HIP(ctx, hipMemcpyAsync(host_acc16_out + 4 * ctx->i_begin, ctx->acc_tmp + ctx->i_begin,
                                ctx->i_count * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
@@ -382,14 +398,14 @@ int nbody_upload_octree(nbody_ctx* ctx, const nbody_octree_node* host_nodes, uin
     if (!ctx || !host_nodes || n_nodes == 0) return ctx ? nb_fail(ctx, NBODY_ERR_INVALID, "nbody_upload_octree: empty tree") : NBODY_ERR_INVALID;
     int r = set_device(ctx);
     if (r) return r;
-    return nb_tree_upload(ctx, host_nodes, n_nodes);
+    return guarded(ctx, [&]() -> int { return nb_tree_upload(ctx, host_nodes, n_nodes); });
 }
 
 int nbody_morton_keys(nbody_ctx* ctx, uint64_t* host_keys, uint8_t* host_leaf_depth, uint32_t* host_order) {
     if (!ctx) return NBODY_ERR_INVALID;
     int r = set_device(ctx);
     if (r) return r;
-    return nb_tree_keys(ctx, host_keys, host_leaf_depth, host_order);
+    return guarded(ctx, [&]() -> int { return nb_tree_keys(ctx, host_keys, host_leaf_depth, host_order); });
 }
 
 int nbody_download(nbody_ctx* ctx, float* host_pos16, float* host_vel16, float* host_acc16) {

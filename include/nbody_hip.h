@@ -184,6 +184,19 @@ int nbody_integrate_ranked(nbody_ctx* ctx);
 /* Forces only (no integration, no swap), for parity checks against src/nbody.wgsl:50-116 and
  * src/nbodybh.wgsl:63-161.  host_acc16_out is f32[N][4]; only this context's targets are written. */
 int nbody_accel_allpairs(nbody_ctx* ctx, float* host_acc16_out);
+/* No counterpart in the reference.  For callers that cannot allocate device memory (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc): the accelerations of
+ * nbody_accel_allpairs, computed by the same kernels, without a context and without any
+ * allocation.  dev_posm is f32[n][4] = {x, y, z, mass} and dev_vel16 f32[n][4] (read by
+ * NBODY_LAW_WGSL_BIAS only, else may be NULL), both device memory on the CURRENT device;
+ * dev_acc16_out, f32[n][4] device memory, receives G * sum (pad lane 0).  Enqueued on `stream`
+ * (a hipStream_t, NULL = the null stream); does not block.  The per-slice partial sums live in a
+ * fixed 16 MiB device array inside the library (one per GPU, held until the process ends), which
+ * limits n_bodies to 131,072: larger inputs return NBODY_ERR_CAPACITY.  Calls that overlap on one
+ * GPU (two streams, two threads) share that array and race; calls on one stream are ordered.
+ * nbody_last_error(NULL) has the message of a failure. */
+int nbody_accel_allpairs_noalloc(const float* dev_posm, const float* dev_vel16, uint64_t n_bodies, int law, float G,
+                                 float eps2, float* dev_acc16_out, void* stream);
 /* Uses the tree currently held by the context (built or uploaded). */
 int nbody_accel_bh(nbody_ctx* ctx, float* host_acc16_out);
 

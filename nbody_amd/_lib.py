@@ -64,6 +64,7 @@ SYMBOLS = {
     "nbody_bh_forces_ranked": (C.c_int, [_P, C.c_uint64, C.c_uint64]),
     "nbody_integrate_ranked": (C.c_int, [_P]),
     "nbody_accel_allpairs": (C.c_int, [_P, _P]),
+    "nbody_accel_allpairs_noalloc": (C.c_int, [_P, _P, C.c_uint64, C.c_int, C.c_float, C.c_float, _P, _P]),
     "nbody_accel_bh": (C.c_int, [_P, _P]),
     "nbody_build_octree": (C.c_int, [_P]),
     "nbody_download_octree": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),

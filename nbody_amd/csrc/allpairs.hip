@@ -424,47 +424,102 @@ uint32_t sym_seg_tiles(const nbody_ctx* ctx, int tpl) {
     return (uint32_t)std::min<uint64_t>(512, std::max<uint64_t>(4, nsb * nt / 2 / 32768));
 }
 
+// Everything a launch of the plain (ordered-pair) kernels needs; no context behind it.
+struct ApLaunch {
+    hipStream_t stream;
+    const float4* posm;
+    const float4* vel;
+    float4* acc_part;  // [slices][i_count]
+    int n, i_begin, i_count;
+    float eps2;
+};
+
 template <int LAW, int IPT>
-void launch_ap(nbody_ctx* ctx, const float4* posm, const float4* vel, int slices, int j_chunk) {
-    dim3 grid((unsigned)((ctx->i_count + BLOCK * IPT - 1) / (BLOCK * IPT)), (unsigned)slices);
-    hipLaunchKernelGGL((k_allpairs<LAW, IPT>), grid, dim3(BLOCK), 0, ctx->stream, posm, vel, ctx->acc_part, (int)ctx->n,
-                       (int)ctx->i_begin, (int)ctx->i_count, j_chunk, ctx->cfg.eps2);
+void launch_ap(const ApLaunch& a, int slices, int j_chunk) {
+    dim3 grid((unsigned)((a.i_count + BLOCK * IPT - 1) / (BLOCK * IPT)), (unsigned)slices);
+    hipLaunchKernelGGL((k_allpairs<LAW, IPT>), grid, dim3(BLOCK), 0, a.stream, a.posm, a.vel, a.acc_part, a.n, a.i_begin,
+                       a.i_count, j_chunk, a.eps2);
 }
 
 template <int IPT>
-void launch_ap_pk(nbody_ctx* ctx, const float4* posm, int slices, int j_chunk) {
-    dim3 grid((unsigned)((ctx->i_count + BLOCK * IPT - 1) / (BLOCK * IPT)), (unsigned)slices);
-    hipLaunchKernelGGL((k_allpairs_plummer_pk<IPT>), grid, dim3(BLOCK), 0, ctx->stream, posm, ctx->acc_part, (int)ctx->n,
-                       (int)ctx->i_begin, (int)ctx->i_count, j_chunk, ctx->cfg.eps2, 0);
+void launch_ap_pk(const ApLaunch& a, int slices, int j_chunk) {
+    dim3 grid((unsigned)((a.i_count + BLOCK * IPT - 1) / (BLOCK * IPT)), (unsigned)slices);
+    hipLaunchKernelGGL((k_allpairs_plummer_pk<IPT>), grid, dim3(BLOCK), 0, a.stream, a.posm, a.acc_part, a.n, a.i_begin,
+                       a.i_count, j_chunk, a.eps2, 0);
 }
 
 template <int IPT>
-void launch_ap_bias_pk(nbody_ctx* ctx, const float4* posm, const float4* vel, int slices, int j_chunk) {
-    dim3 grid((unsigned)((ctx->i_count + BLOCK * IPT - 1) / (BLOCK * IPT)), (unsigned)slices);
-    hipLaunchKernelGGL((k_allpairs_plummer_pk<IPT, true>), grid, dim3(BLOCK), 0, ctx->stream, posm, ctx->acc_part,
-                       (int)ctx->n, (int)ctx->i_begin, (int)ctx->i_count, j_chunk, ctx->cfg.eps2, 0, vel);
+void launch_ap_bias_pk(const ApLaunch& a, int slices, int j_chunk) {
+    dim3 grid((unsigned)((a.i_count + BLOCK * IPT - 1) / (BLOCK * IPT)), (unsigned)slices);
+    hipLaunchKernelGGL((k_allpairs_plummer_pk<IPT, true>), grid, dim3(BLOCK), 0, a.stream, a.posm, a.acc_part, a.n,
+                       a.i_begin, a.i_count, j_chunk, a.eps2, 0, a.vel);
 }
 
 template <int LAW>
-void launch_ap_ipt(nbody_ctx* ctx, const float4* posm, const float4* vel, int ipt, int slices, int j_chunk) {
+void launch_ap_ipt(const ApLaunch& a, int ipt, int slices, int j_chunk) {
     if (LAW == NBODY_LAW_WGSL_BIAS && ipt >= 2 && !env_int("NBODY_AP_NOPACK", 0)) {
-        if (ipt == 2) launch_ap_bias_pk<2>(ctx, posm, vel, slices, j_chunk);
-        else launch_ap_bias_pk<4>(ctx, posm, vel, slices, j_chunk);
+        if (ipt == 2) launch_ap_bias_pk<2>(a, slices, j_chunk);
+        else launch_ap_bias_pk<4>(a, slices, j_chunk);
         return;
     }
     if (LAW == NBODY_LAW_PLUMMER && ipt >= 2 && !env_int("NBODY_AP_NOPACK", 0)) {
         switch (ipt) {
-            case 2: launch_ap_pk<2>(ctx, posm, slices, j_chunk); return;
-            case 8: launch_ap_pk<8>(ctx, posm, slices, j_chunk); return;
-            default: launch_ap_pk<4>(ctx, posm, slices, j_chunk); return;
+            case 2: launch_ap_pk<2>(a, slices, j_chunk); return;
+            case 8: launch_ap_pk<8>(a, slices, j_chunk); return;
+            default: launch_ap_pk<4>(a, slices, j_chunk); return;
         }
     }
     switch (ipt) {
-        case 1: launch_ap<LAW, 1>(ctx, posm, vel, slices, j_chunk); break;
-        case 2: launch_ap<LAW, 2>(ctx, posm, vel, slices, j_chunk); break;
-        case 8: launch_ap<LAW, 8>(ctx, posm, vel, slices, j_chunk); break;
-        default: launch_ap<LAW, 4>(ctx, posm, vel, slices, j_chunk); break;
+        case 1: launch_ap<LAW, 1>(a, slices, j_chunk); break;
+        case 2: launch_ap<LAW, 2>(a, slices, j_chunk); break;
+        case 8: launch_ap<LAW, 8>(a, slices, j_chunk); break;
+        default: launch_ap<LAW, 4>(a, slices, j_chunk); break;
     }
+}
+
+// Targets per lane, source slices and slice length of the plain kernels for i_count targets
+// against n sources; at most max_slices slices (what the partial-sum buffer can hold).
+struct ApPlan {
+    int ipt, slices, j_chunk;
+};
+ApPlan ap_plan(uint64_t n, uint64_t i_count, int num_cus, uint64_t max_slices_fit) {
+    ApPlan pl;
+    pl.ipt = env_int("NBODY_AP_IPT", 0);
+    if (pl.ipt != 1 && pl.ipt != 2 && pl.ipt != 4 && pl.ipt != 8) {
+        // four targets per lane measured best down to N = 65,536 (source slices fill the chip);
+        // fewer only when there are not even that many targets
+        pl.ipt = i_count >= 16384 ? 4 : i_count >= 4096 ? 2 : 1;
+    }
+    const uint64_t tblocks = (i_count + BLOCK * pl.ipt - 1) / (BLOCK * pl.ipt);
+    int slices = env_int("NBODY_AP_SLICES", 0);
+    const int max_slices = (int)std::max<uint64_t>(1, (n + TJ - 1) / TJ);
+    if (slices <= 0) {
+        // aim at >= 16 workgroups per CU in total (measured best at N = 65,536 and 1,048,576)
+        uint64_t want = (uint64_t)num_cus * 16;
+        slices = (int)std::min<uint64_t>(64, (want + tblocks - 1) / tblocks);
+    }
+    slices = std::max(1, std::min(slices, max_slices));
+    slices = (int)std::min<uint64_t>((uint64_t)slices, std::max<uint64_t>(1, max_slices_fit));
+    // slice length: a whole number of tiles
+    uint64_t tiles = (n + TJ - 1) / TJ;
+    uint64_t tiles_per_slice = (tiles + slices - 1) / slices;
+    pl.j_chunk = (int)(tiles_per_slice * TJ);
+    pl.slices = (int)((n + pl.j_chunk - 1) / pl.j_chunk);
+    return pl;
+}
+
+// The force kernel of `law` over the plan's slices; ap_finalize then writes their f64 sums times G.
+void ap_forces_plain(const ApLaunch& a, int law, const ApPlan& pl) {
+    switch (law) {
+        case NBODY_LAW_CPU_R6: launch_ap_ipt<NBODY_LAW_CPU_R6>(a, pl.ipt, pl.slices, pl.j_chunk); break;
+        case NBODY_LAW_WGSL_BIAS: launch_ap_ipt<NBODY_LAW_WGSL_BIAS>(a, pl.ipt, pl.slices, pl.j_chunk); break;
+        default: launch_ap_ipt<NBODY_LAW_PLUMMER>(a, pl.ipt, pl.slices, pl.j_chunk); break;
+    }
+}
+void ap_finalize(const ApLaunch& a, int law, const ApPlan& pl, float G, float4* acc_out) {
+    const float g = (law == NBODY_LAW_CPU_R6) ? 0.0066743f : G;
+    unsigned fb = (unsigned)((a.i_count + 255) / 256);
+    hipLaunchKernelGGL(k_finalize, dim3(fb), dim3(256), 0, a.stream, a.acc_part, pl.slices, a.i_begin, a.i_count, g, acc_out);
 }
 
 }  // namespace
@@ -540,46 +595,24 @@ int nb_allpairs_forces(nbody_ctx* ctx, const float4* posm_in, const float4* vel_
         if (have || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need < free_b / 2))
             return nb_allpairs_forces_sym(ctx, posm_in, acc_out, seg, tpl, 0, 1);
     }
-    int ipt = env_int("NBODY_AP_IPT", 0);
-    if (ipt != 1 && ipt != 2 && ipt != 4 && ipt != 8) {
-        // four targets per lane measured best down to N = 65,536 (source slices fill the chip);
-        // fewer only when there are not even that many targets
-        ipt = ctx->i_count >= 16384 ? 4 : ctx->i_count >= 4096 ? 2 : 1;
-    }
-    const uint64_t tblocks = (ctx->i_count + BLOCK * ipt - 1) / (BLOCK * ipt);
-    int slices = env_int("NBODY_AP_SLICES", 0);
-    const int max_slices = (int)std::max<uint64_t>(1, (ctx->n + TJ - 1) / TJ);
-    if (slices <= 0) {
-        // aim at >= 16 workgroups per CU in total (measured best at N = 65,536 and 1,048,576)
-        uint64_t want = (uint64_t)ctx->num_cus * 16;
-        slices = (int)std::min<uint64_t>(64, (want + tblocks - 1) / tblocks);
-    }
-    slices = std::max(1, std::min(slices, max_slices));
-    // slice length: a whole number of tiles
-    uint64_t tiles = (ctx->n + TJ - 1) / TJ;
-    uint64_t tiles_per_slice = (tiles + slices - 1) / slices;
-    int j_chunk = (int)(tiles_per_slice * TJ);
-    slices = (int)((ctx->n + j_chunk - 1) / j_chunk);
-
-    if ((uint64_t)slices > ctx->acc_part_slices) {
+    const ApPlan pl = ap_plan(ctx->n, ctx->i_count, ctx->num_cus, ~0ull);
+    if ((uint64_t)pl.slices > ctx->acc_part_slices) {
         if (ctx->acc_part) NB_HIP(ctx, hipFree(ctx->acc_part));
         ctx->acc_part = nullptr;
-        NB_HIP(ctx, hipMalloc(&ctx->acc_part, (size_t)slices * ctx->i_count * sizeof(float4)));
-        ctx->acc_part_slices = slices;
+        ctx->acc_part_slices = 0;
+        if (hipMalloc(&ctx->acc_part, (size_t)pl.slices * ctx->i_count * sizeof(float4)) != hipSuccess) {
+            ctx->acc_part = nullptr;
+            (void)hipGetLastError();
+            return nb_fail(ctx, NBODY_ERR_NOMEM, "all-pairs partial sums: out of device memory");
+        }
+        ctx->acc_part_slices = pl.slices;
     }
-
+    const ApLaunch a{ctx->stream, posm_in, vel_in, ctx->acc_part, (int)ctx->n, (int)ctx->i_begin, (int)ctx->i_count, ctx->cfg.eps2};
     nb_time_begin(ctx, 0);
-    switch (law) {
-        case NBODY_LAW_CPU_R6: launch_ap_ipt<NBODY_LAW_CPU_R6>(ctx, posm_in, vel_in, ipt, slices, j_chunk); break;
-        case NBODY_LAW_WGSL_BIAS: launch_ap_ipt<NBODY_LAW_WGSL_BIAS>(ctx, posm_in, vel_in, ipt, slices, j_chunk); break;
-        default: launch_ap_ipt<NBODY_LAW_PLUMMER>(ctx, posm_in, vel_in, ipt, slices, j_chunk); break;
-    }
+    ap_forces_plain(a, law, pl);
     nb_time_end(ctx, 0);
     NB_HIP(ctx, hipGetLastError());
-    const float G = (law == NBODY_LAW_CPU_R6) ? 0.0066743f : ctx->cfg.G;
-    unsigned fb = (unsigned)((ctx->i_count + 255) / 256);
-    hipLaunchKernelGGL(k_finalize, dim3(fb), dim3(256), 0, ctx->stream, ctx->acc_part, slices, (int)ctx->i_begin,
-                       (int)ctx->i_count, G, acc_out);
+    ap_finalize(a, law, pl, ctx->cfg.G, acc_out);
     NB_HIP(ctx, hipGetLastError());
     ctx->counters.interactions_allpairs +=
         (law == NBODY_LAW_CPU_R6) ? ctx->i_count * (ctx->n - 1) : ctx->i_count * ctx->n;
@@ -636,5 +669,68 @@ int nb_energy(nbody_ctx* ctx, double* kinetic, double* potential) {
     NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (kinetic) *kinetic = h[0];
     if (potential) *potential = -0.5 * (double)ctx->cfg.G * h[1];
+    return NBODY_OK;
+}
+
+// ---- all-pairs accelerations without any allocation ---------------------------------------------
+// For callers that cannot allocate device memory (HIP graph capture, tight serving loops, harnesses
+// that forbid it): the same plain kernels as nbody_accel_allpairs, with the per-slice partial sums
+// in a fixed device array instead of a buffer grown on demand.  Every GPU the library runs on
+// holds its own copy of that array until the process ends.
+namespace {
+constexpr uint64_t NOALLOC_MAX_BODIES = 131072;
+constexpr size_t NOALLOC_SCRATCH_BYTES = 16u << 20;  // 16 MiB: 8 slices at the largest N, 64 up to N = 16,384
+constexpr int NOALLOC_MAX_DEVICES = 64;
+}  // namespace
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+namespace {
+// Device address of `scratch` on each GPU (the array's name is only a host-side handle); looked up
+// on the first call with that GPU current.  Plain loads and stores of an aligned pointer; two
+// threads racing on the first call both store the same value.
+void* g_scratch_ptr[NOALLOC_MAX_DEVICES] = {};
+int g_scratch_cus[NOALLOC_MAX_DEVICES] = {};
+thread_local const char* g_noalloc_error = "";
+int noalloc_fail(int code, const char* msg) {
+    g_noalloc_error = msg;
+    return code;
+}
+}  // namespace
+
+const char* nb_noalloc_last_error() { return g_noalloc_error; }
+void nb_noalloc_clear_error() { g_noalloc_error = ""; }
+
+extern "C" int nbody_accel_allpairs_noalloc(const float* dev_posm, const float* dev_vel16, uint64_t n_bodies, int law, float G,
+                                            float eps2, float* dev_acc16_out, void* stream) {
+    if (!dev_posm || !dev_acc16_out) return noalloc_fail(NBODY_ERR_INVALID, "nbody_accel_allpairs_noalloc: null buffer");
+    if (law < 0 || law > 2) return noalloc_fail(NBODY_ERR_INVALID, "nbody_accel_allpairs_noalloc: unknown law");
+    if (law == NBODY_LAW_WGSL_BIAS && !dev_vel16)
+        return noalloc_fail(NBODY_ERR_INVALID, "nbody_accel_allpairs_noalloc: the WGSL_BIAS law needs the velocities");
+    if (n_bodies == 0 || n_bodies > NOALLOC_MAX_BODIES)
+        return noalloc_fail(NBODY_ERR_CAPACITY, "nbody_accel_allpairs_noalloc: n_bodies must be in [1, 131072]");
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return noalloc_fail(NBODY_ERR_NO_DEVICE, "nbody_accel_allpairs_noalloc: no current HIP device");
+    if (dev < 0 || dev >= NOALLOC_MAX_DEVICES)
+        return noalloc_fail(NBODY_ERR_NO_DEVICE, "nbody_accel_allpairs_noalloc: device ordinal out of range");
+    if (!g_scratch_ptr[dev]) {
+        void* ptr = nullptr;
+        if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)) != hipSuccess || !ptr)
+            return noalloc_fail(NBODY_ERR_HIP, "nbody_accel_allpairs_noalloc: hipGetSymbolAddress(scratch) failed");
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        g_scratch_cus[dev] = cus;
+        g_scratch_ptr[dev] = ptr;
+    }
+    float4* part = reinterpret_cast<float4*>(g_scratch_ptr[dev]);
+    const ApPlan pl = ap_plan(n_bodies, n_bodies, g_scratch_cus[dev], NOALLOC_SCRATCH_BYTES / (n_bodies * sizeof(float4)));
+    if ((uint64_t)pl.slices * n_bodies * sizeof(float4) > NOALLOC_SCRATCH_BYTES)
+        return noalloc_fail(NBODY_ERR_CAPACITY, "nbody_accel_allpairs_noalloc: partial sums do not fit the fixed scratch");
+    const ApLaunch a{(hipStream_t)stream, reinterpret_cast<const float4*>(dev_posm), reinterpret_cast<const float4*>(dev_vel16),
+                     part, (int)n_bodies, 0, (int)n_bodies, eps2};
+    // every slice of every target is written by the force kernel before the sum reads it: nothing
+    // of the previous call's contents is read, so the array needs no clearing
+    ap_forces_plain(a, law, pl);
+    if (hipGetLastError() != hipSuccess) return noalloc_fail(NBODY_ERR_HIP, "nbody_accel_allpairs_noalloc: force kernel launch failed");
+    ap_finalize(a, law, pl, G, reinterpret_cast<float4*>(dev_acc16_out));
+    if (hipGetLastError() != hipSuccess) return noalloc_fail(NBODY_ERR_HIP, "nbody_accel_allpairs_noalloc: sum kernel launch failed");
     return NBODY_OK;
 }

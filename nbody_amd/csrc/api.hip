@@ -91,7 +91,12 @@ extern "C" {
 
 const char* nbody_version(void) { return "nbody_hip 0.1 (gfx950)"; }
 
-const char* nbody_last_error(const nbody_ctx* ctx) { return ctx ? ctx->err.c_str() : g_nbody_create_error.c_str(); }
+const char* nbody_last_error(const nbody_ctx* ctx) {
+    if (ctx) return ctx->err.c_str();
+    // calls without a context: nbody_create, or nbody_accel_allpairs_noalloc if that failed since
+    const char* m = nb_noalloc_last_error();
+    return *m ? m : g_nbody_create_error.c_str();
+}
 
 void nbody_config_default(nbody_config* cfg) {
     if (!cfg) return;
@@ -118,6 +123,7 @@ int nbody_create(nbody_ctx** out, const nbody_config* cfg) {
         return NBODY_ERR_INVALID;
     }
     *out = nullptr;
+    nb_noalloc_clear_error();
     if (cfg->n_bodies == 0 || cfg->n_bodies > (1ull << 30)) {
         g_nbody_create_error = "nbody_create: n_bodies must be in [1, 2^30]";
         return NBODY_ERR_INVALID;

@@ -80,6 +80,9 @@ void nb_time_begin(nbody_ctx* ctx, int which);
 void nb_time_end(nbody_ctx* ctx, int which);
 int nb_time_collect(nbody_ctx* ctx, int which);
 
+const char* nb_noalloc_last_error();
+void nb_noalloc_clear_error();
+
 // symmetric all-pairs (allpairs_sym.hip)
 int nb_allpairs_forces_sym(nbody_ctx* ctx, const float4* posm_in, float4* acc_out, uint32_t seg_tiles, int tpl,
                            uint32_t part, uint32_t nparts);

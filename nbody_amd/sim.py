@@ -83,6 +83,14 @@ def gen_plummer(n, seed=42, world=250.0, a=12.5, rmax=100.0, total_mass=4515.625
     return m, p, v
 
 
+def accel_allpairs_noalloc(dev_posm, dev_vel16, n_bodies, law, G, eps2, dev_acc16_out, stream=None):
+    """nbody_accel_allpairs_noalloc on raw device addresses (ints): allocates nothing, does not block."""
+    lib = _lib.load()
+    rc = lib.nbody_accel_allpairs_noalloc(dev_posm, dev_vel16, n_bodies, law, G, eps2, dev_acc16_out, stream)
+    if rc:
+        raise NBodyError(rc, lib.nbody_last_error(None).decode())
+
+
 class NBodySim:
     def __init__(self, n_bodies, **cfg):
         self.lib = _lib.load()

@@ -110,6 +110,8 @@ extern "C" {
     pub fn nbody_bh_forces_ranked(ctx: *mut nbody_ctx, rank_begin: u64, rank_count: u64) -> c_int;
     pub fn nbody_integrate_ranked(ctx: *mut nbody_ctx) -> c_int;
     pub fn nbody_accel_allpairs(ctx: *mut nbody_ctx, host_acc16_out: *mut f32) -> c_int;
+    /// No counterpart in the reference: for callers that cannot allocate device memory.
+    pub fn nbody_accel_allpairs_noalloc(dev_posm: *const f32, dev_vel16: *const f32, n_bodies: u64, law: c_int, g: f32, eps2: f32, dev_acc16_out: *mut f32, stream: *mut c_void) -> c_int;
     pub fn nbody_accel_bh(ctx: *mut nbody_ctx, host_acc16_out: *mut f32) -> c_int;
     pub fn nbody_build_octree(ctx: *mut nbody_ctx) -> c_int;
     pub fn nbody_download_octree(ctx: *mut nbody_ctx, host_nodes: *mut nbody_octree_node, cap_nodes: u64, n_nodes: *mut u64) -> c_int;

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnbody_hip.so")
+LIB_PATH = os.environ.get("NBODY_HIP_LIB") or os.path.join(_HERE, "libnbody_hip.so")  # the override is for measurement builds
 
 
 class NBodyConfig(C.Structure):

@@ -789,8 +789,11 @@ __device__ __forceinline__ void pin_moment(const QMoment& m) {
     asm volatile("" ::"s"(m.xx), "s"(m.xy), "s"(m.xz), "s"(m.yy), "s"(m.yz), "s"(m.zz));
 }
 
+// Seven wavefronts per SIMD (at most 96 scalar registers; the few that do not fit live in lanes of
+// a vector register): measured 4 % faster at N = 16M than the six the unconstrained allocation
+// (106) is admitted with; eight (80) spills 73 of them and is twice as slow.
 template <int LAW, bool COUNT, bool QUAD>
-__global__ __launch_bounds__(WALK_THREADS) void k_walk(const QNode* __restrict__ q, const uint32_t* __restrict__ order, uint32_t m,
+__global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_walk(const QNode* __restrict__ q, const uint32_t* __restrict__ order, uint32_t m,
                                               uint32_t i_begin, const float4* __restrict__ posm,
                                               const float4* __restrict__ vel, float4* __restrict__ acc_out, float G,
                                               float eps2, float theta, const float* __restrict__ range,
@@ -953,226 +956,6 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk(const QNode* __restrict__
     }
 }
 
-// ---- traversal, batch form ------------------------------------------------------------------
-// The same traversal (same stack, same lane masks, same decisions) with the records of a batch
-// handled in three straight-line passes instead of one record at a time:
-//   1. separations, squared distances and the "clearly accepted" lane sets of all records
-//   2. the force terms of all records (every lane evaluates; lanes outside a record's set add zero)
-//   3. the descent: per record one scalar test "did every lane of the group accept it?"; only
-//      where that fails are the "clearly open" compare and the stack push reached
-// Independent chains of the records interleave in passes 1 and 2, and the per-record scalar work
-// of the common case is one instruction and one untaken branch.  A record with lanes inside the
-// band between its two thresholds is noted and settled afterwards, one record at a time, by the
-// reference's own expression (src/nbodybh.wgsl:104-106): lanes that accept it get its term,
-// the others are pushed as a second entry for the same node (lane sets of entries stay disjoint).
-__device__ __forceinline__ unsigned long long lanes_nv(bool p) {
-    unsigned long long m = __ballot(p);
-    asm("" : "+s"(m));
-    return m;
-}
-
-struct WalkCounts {
-    uint32_t visit = 0, leaf = 0, agg = 0, wave = 0, max_top = 0;
-};
-
-template <int LAW, bool COUNT, int NB>
-__device__ __forceinline__ uint32_t walk_batch(const QNode (&c)[WALK_BATCH], unsigned long long mask, const Tgt& t, float eps2,
-                                               float& ax, float& ay, float& az, uint4* stack, int& top, WalkCounts& cn,
-                                               int lane) {
-    float dx[NB], dy[NB], dz[NB], r2[NB];
-    unsigned long long acc[NB];
-#pragma unroll
-    for (int k = 0; k < NB; ++k) {
-        dx[k] = c[k].cx - t.x;
-        dy[k] = c[k].cy - t.y;
-        dz[k] = c[k].cz - t.z;
-        // PLUMMER: the softened squared distance, which the thresholds are prepared for
-        r2[k] = LAW == NBODY_LAW_PLUMMER ? fmaf(dx[k], dx[k], fmaf(dy[k], dy[k], fmaf(dz[k], dz[k], eps2)))
-                                         : fmaf(dx[k], dx[k], fmaf(dy[k], dy[k], dz[k] * dz[k]));
-        // src/nbodybh.wgsl:104-106 by the node's squared-distance thresholds; a LEAFBODY record (a
-        // direct interaction, src/nbodybh.wgsl:76-102) carries thresholds below zero
-        acc[k] = lanes_nv(r2[k] > c[k].r2_accept);
-    }
-    const bool in = __builtin_amdgcn_inverse_ballot_w64(mask);
-    if (LAW == NBODY_LAW_PLUMMER) {
-        // src/nbody.wgsl:56-65 for every record and lane; the group's lanes then keep the batch's sum
-        float bx = 0.0f, by = 0.0f, bz = 0.0f;
-#pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            const float ri = WALK_PRECISE ? rsq_refined(r2[k]) : __builtin_amdgcn_rsqf(r2[k]);
-            const float sc = (c[k].mass * ri) * (ri * ri);
-            const float w = __builtin_amdgcn_inverse_ballot_w64(acc[k]) ? sc : 0.0f;
-            bx = fmaf(w, dx[k], bx);
-            by = fmaf(w, dy[k], by);
-            bz = fmaf(w, dz[k], bz);
-        }
-        ax += in ? bx : 0.0f;
-        ay += in ? by : 0.0f;
-        az += in ? bz : 0.0f;
-    } else {
-#pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            const unsigned long long take = acc[k] & mask;
-            if (take) {
-                const float sc = pair_scale<LAW, WALK_PRECISE>(t, dx[k], dy[k], dz[k], r2[k], c[k].mass, eps2);
-                const float w = __builtin_amdgcn_inverse_ballot_w64(take) ? sc : 0.0f;
-                ax = fmaf(w, dx[k], ax);
-                ay = fmaf(w, dy[k], ay);
-                az = fmaf(w, dz[k], az);
-            }
-        }
-    }
-    if (COUNT) {
-        cn.wave += lane == 0 ? NB : 0;
-        cn.visit += in ? NB : 0;
-#pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            const uint32_t tk = __builtin_amdgcn_inverse_ballot_w64(acc[k] & mask) ? 1u : 0u;
-            if (qn_type(c[k]) == NBODY_NODE_LEAFBODY) cn.leaf += tk;
-            else cn.agg += tk;
-        }
-    }
-    uint32_t ubits = 0;
-#pragma unroll
-    for (int k = 0; k < NB; ++k) {
-        const unsigned long long rest = mask & ~acc[k];
-        if (__builtin_expect(rest != 0, 0)) {
-            const unsigned long long open = rest & lanes_nv(r2[k] < c[k].r2_open);
-            if (open != rest) ubits |= 1u << k;
-            if (open) {
-                // INTERIOR: its children; LEAFLIST: its members (LEAFBODY records, src/nbodybh.wgsl:137-146)
-                stack[top] = make_uint4(c[k].first, qn_count(c[k]), (uint32_t)open, (uint32_t)(open >> 32));
-                ++top;
-            }
-        }
-    }
-    return ubits;
-}
-
-constexpr int WALK2_STACK = 224;  // a batch may push twice per record (see above)
-
-template <int LAW, bool COUNT>
-__global__ __launch_bounds__(WALK_THREADS) void k_walk_batched(const QNode* __restrict__ q, const uint32_t* __restrict__ order,
-                                                              uint32_t m, uint32_t i_begin, const float4* __restrict__ posm,
-                                                              const float4* __restrict__ vel, float4* __restrict__ acc_out,
-                                                              float G, float eps2, float theta, const float* __restrict__ range,
-                                                              unsigned long long* __restrict__ counters,
-                                                              uint32_t* __restrict__ err_flag, int out_by_rank) {
-    __shared__ uint4 stack[WALK2_STACK];  // {first, count, mask.lo, mask.hi}
-    const int lane = threadIdx.x;
-    // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2): give each XCD one
-    // contiguous eighth of the Morton order, so that it keeps meeting the same part of the tree.
-    const uint32_t nblk = gridDim.x, q8 = nblk / 8, r8 = nblk % 8;
-    const uint32_t xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
-    const uint32_t blk = xcd * q8 + min(xcd, r8) + slot;
-    const uint32_t r = blk * WALK_THREADS + lane;
-    const bool valid = r < m;
-    const uint32_t b = valid ? (order ? order[r] : i_begin + r) : 0u;
-    Tgt t;
-    {
-        const float4 p = posm[b];
-        t.x = p.x; t.y = p.y; t.z = p.z;
-        t.idx = (int)b;
-        t.vx = t.vy = t.vz = t.vn = 0.0f;
-        if (LAW == NBODY_LAW_WGSL_BIAS) {
-            const float4 v = vel[b];
-            t.vx = v.x; t.vy = v.y; t.vz = v.z;
-            t.vn = sqrtf(fmaf(v.x, v.x, fmaf(v.y, v.y, v.z * v.z)));
-        }
-    }
-    float ax = 0.0f, ay = 0.0f, az = 0.0f;
-    WalkCounts cn;
-    int top = 0;
-    const unsigned long long all = __ballot(valid);
-    if (all) {
-        stack[0] = make_uint4(0u, 1u, (uint32_t)all, (uint32_t)(all >> 32));  // the root as a one-node group
-        top = 1;
-    }
-    while (top > 0) {
-        --top;
-        const uint4 e = stack[top];
-        const uint32_t first = __builtin_amdgcn_readfirstlane(e.x);
-        const uint32_t cnt = __builtin_amdgcn_readfirstlane(e.y);
-        const uint32_t mlo = (uint32_t)__builtin_amdgcn_readfirstlane(e.z);
-        const uint32_t mhi = (uint32_t)__builtin_amdgcn_readfirstlane(e.w);
-        const unsigned long long mask = ((unsigned long long)mhi << 32) | (unsigned long long)mlo;
-        for (uint32_t b0 = 0; b0 < cnt; b0 += WALK_BATCH) {
-            const uint32_t nb = min((uint32_t)WALK_BATCH, cnt - b0);
-            // All records of the batch are fetched before the first use, from consecutive
-            // addresses whether the group has that many or not (the array is padded).
-            QNode c[WALK_BATCH];
-            const QNode* group = q + (first + b0);
-#pragma unroll
-            for (int k = 0; k < WALK_BATCH; ++k) c[k] = group[k];
-#pragma unroll
-            for (int k = 0; k < WALK_BATCH; ++k) pin_record(c[k]);
-            if (top + 2 * WALK_BATCH > WALK2_STACK) {
-                if (lane == 0) *err_flag = 2;
-                top = 0;
-                break;
-            }
-            uint32_t ubits = 0;
-            switch (nb) {
-                case 1: ubits = walk_batch<LAW, COUNT, 1>(c, mask, t, eps2, ax, ay, az, stack, top, cn, lane); break;
-                case 2: ubits = walk_batch<LAW, COUNT, 2>(c, mask, t, eps2, ax, ay, az, stack, top, cn, lane); break;
-                case 3: ubits = walk_batch<LAW, COUNT, 3>(c, mask, t, eps2, ax, ay, az, stack, top, cn, lane); break;
-                case 4: ubits = walk_batch<LAW, COUNT, 4>(c, mask, t, eps2, ax, ay, az, stack, top, cn, lane); break;
-                case 5: ubits = walk_batch<LAW, COUNT, 5>(c, mask, t, eps2, ax, ay, az, stack, top, cn, lane); break;
-                case 6: ubits = walk_batch<LAW, COUNT, 6>(c, mask, t, eps2, ax, ay, az, stack, top, cn, lane); break;
-                case 7: ubits = walk_batch<LAW, COUNT, 7>(c, mask, t, eps2, ax, ay, az, stack, top, cn, lane); break;
-                default: ubits = walk_batch<LAW, COUNT, 8>(c, mask, t, eps2, ax, ay, az, stack, top, cn, lane); break;
-            }
-            if (__builtin_expect(ubits != 0, 0)) {
-                // records with lanes in the band between the thresholds: the reference's expression decides
-#pragma unroll 1
-                for (uint32_t k = 0; k < nb; ++k) {
-                    if (!((ubits >> k) & 1u)) continue;
-                    const QNode nd = q[first + b0 + k];
-                    const float dx = nd.cx - t.x, dy = nd.cy - t.y, dz = nd.cz - t.z;
-                    const float r2 = LAW == NBODY_LAW_PLUMMER ? fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, eps2)))
-                                                              : fmaf(dx, dx, fmaf(dy, dy, dz * dz));
-                    const unsigned long long unsure = mask & ~lanes(r2 > nd.r2_accept) & ~lanes(r2 < nd.r2_open);
-                    const float rg = range[first + b0 + k];
-                    const float rr = sqrtf(((dx * dx) + (dy * dy)) + (dz * dz));  // distance(pos, com)
-                    const unsigned long long yes = unsure & lanes((rg / rr) < theta);
-                    const unsigned long long no = unsure & ~yes;
-                    if (yes) {
-                        float sc;
-                        if (LAW == NBODY_LAW_PLUMMER) {
-                            const float ri = WALK_PRECISE ? rsq_refined(r2) : __builtin_amdgcn_rsqf(r2);
-                            sc = (nd.mass * ri) * (ri * ri);
-                        } else {
-                            sc = pair_scale<LAW, WALK_PRECISE>(t, dx, dy, dz, r2, nd.mass, eps2);
-                        }
-                        const float w = __builtin_amdgcn_inverse_ballot_w64(yes) ? sc : 0.0f;
-                        ax = fmaf(w, dx, ax);
-                        ay = fmaf(w, dy, ay);
-                        az = fmaf(w, dz, az);
-                        if (COUNT) {
-                            const uint32_t tk = __builtin_amdgcn_inverse_ballot_w64(yes) ? 1u : 0u;
-                            if (qn_type(nd) == NBODY_NODE_LEAFBODY) cn.leaf += tk;
-                            else cn.agg += tk;
-                        }
-                    }
-                    if (no) {
-                        stack[top] = make_uint4(nd.first, qn_count(nd), (uint32_t)no, (uint32_t)(no >> 32));
-                        ++top;
-                    }
-                }
-            }
-            if (COUNT) cn.max_top = max(cn.max_top, (uint32_t)top);
-        }
-    }
-    if (valid) acc_out[out_by_rank ? i_begin + r : b] = make_float4(G * ax, G * ay, G * az, 0.0f);
-    if (COUNT) {
-        atomicAdd(&counters[0], (unsigned long long)cn.visit);
-        atomicAdd(&counters[1], (unsigned long long)cn.leaf);
-        atomicAdd(&counters[2], (unsigned long long)cn.agg);
-        atomicAdd(&counters[3], (unsigned long long)cn.wave);
-        atomicMax(&counters[4], (unsigned long long)cn.max_top);
-    }
-}
-
 // theta == 0 gives infinite (or, for a zero range, NaN) thresholds: nothing is accepted by
 // them and the reference's expression, evaluated in the band, opens every node as it should.
 MacScale mac_scale(const nbody_ctx* ctx) {
@@ -1233,23 +1016,14 @@ void launch_walk(nbody_ctx* ctx, Octree* T, const uint32_t* order, uint32_t m, c
     hipLaunchKernelGGL((k_walk<LAW, COUNT, QUAD>), grid, dim3(WALK_THREADS), 0, ctx->stream, T->nodes, order, m, i_begin, posm, \
                        vel, acc_out, ctx->cfg.G, ctx->cfg.eps2, ctx->cfg.theta, T->range,                                 \
                        (unsigned long long*)T->walk_counters, T->err_flag, out_by_rank, T->quad)
-#define NB_WALK2(COUNT)                                                                                                   \
-    hipLaunchKernelGGL((k_walk_batched<LAW, COUNT>), grid, dim3(WALK_THREADS), 0, ctx->stream, T->nodes, order, m, i_begin, \
-                       posm, vel, acc_out, ctx->cfg.G, ctx->cfg.eps2, ctx->cfg.theta, T->range,                           \
-                       (unsigned long long*)T->walk_counters, T->err_flag, out_by_rank)
-    static const bool old_walk = getenv("NBODY_WALK_BATCHED") == nullptr;  // the batch form is measured slower so far
-    if (quad) {
-        if (ctx->counting) NB_WALK(true, true);
-        else NB_WALK(false, true);
-    } else if (old_walk) {
-        if (ctx->counting) NB_WALK(true, false);
-        else NB_WALK(false, false);
+    if (ctx->counting) {
+        if (quad) NB_WALK(true, true);
+        else NB_WALK(true, false);
     } else {
-        if (ctx->counting) NB_WALK2(true);
-        else NB_WALK2(false);
+        if (quad) NB_WALK(false, true);
+        else NB_WALK(false, false);
     }
 #undef NB_WALK
-#undef NB_WALK2
 }
 
 }  // namespace

@@ -1,4 +1,4 @@
-"""Barnes-Hut traversal timing at one size; NBODY_WALK_BATCHED=1 selects the batch-form kernel."""
+"""Barnes-Hut traversal and build timing at the given sizes (NBODY_HIP_LIB selects a measurement build)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -115,7 +115,10 @@ enum nbody_buffer {
     NBODY_BUF_ACC = 2,   /* current accelerations f32[N][4] */
     NBODY_BUF_OCTREE = 3, /* nbody_octree_node[n_nodes], exported on request */
     NBODY_BUF_ACC_PARTIAL = 4 /* f32[N][4] exchanged between GPUs: written by nbody_allpairs_partial (read by
-                                 nbody_integrate_partial) or by nbody_bh_forces_ranked (read by nbody_integrate_ranked) */
+                                 nbody_integrate_partial) or by nbody_bh_forces_ranked (read by nbody_integrate_ranked).
+                                 Every step and every nbody_accel_* call also writes it: an integrate_* call
+                                 that does not follow its own force call directly returns NBODY_ERR_STATE.
+                                 Uploads and downloads do not touch it. */
 };
 
 /* Work done since nbody_create or the last nbody_counters_reset; for roofline arithmetic. */
@@ -129,7 +132,10 @@ typedef struct nbody_counters_t {
     uint64_t bh_wave_node_visits;   /* per-wavefront node visits of the last counted walk */
     uint64_t octree_nodes;          /* nodes of the last built tree */
     uint64_t bh_max_stack;          /* deepest traversal stack of the last counted walk */
-    uint64_t reserved[7];
+    uint64_t allpairs_path;         /* kernel of the last all-pairs force evaluation: 1 = one evaluation per ordered
+                                       pair, 2 = the pair kernel (one per unordered pair; PLUMMER law, N >= 65,536,
+                                       scratch permitting), 0 = none yet */
+    uint64_t reserved[6];
 } nbody_counters_t;
 
 const char* nbody_version(void);
@@ -153,7 +159,8 @@ int nbody_upload_alt(nbody_ctx* ctx, const float* host_pos16, const float* host_
 /* Replaces one MainEventsCleared tick of src/nbody_gpu.rs:418-451 (or of src/nbody_cpu.rs:319-360
  * with NBODY_INT_CPU_EULER_XBUF), nsteps times: forces over all N sources for this context's
  * targets, integration, swap of the in/out sets.  With shard_count < N only nsteps == 1 is
- * accepted: the host must all-gather NBODY_BUF_POSM between steps. */
+ * accepted unless the context has a communicator (nbody_comm_init): the host must all-gather
+ * NBODY_BUF_POSM between steps. */
 int nbody_step_allpairs(nbody_ctx* ctx, int nsteps);
 /* Replaces one tick of src/nbody_gpu_bh.rs:445-527: octree build from the current positions,
  * traversal, integration with clamp to [0,world]^3, swap.  The laws are those of
@@ -180,6 +187,25 @@ int nbody_integrate_partial(nbody_ctx* ctx);
  * so positions need no exchange.  No counterpart in the reference (single device). */
 int nbody_bh_forces_ranked(nbody_ctx* ctx, uint64_t rank_begin, uint64_t rank_count);
 int nbody_integrate_ranked(nbody_ctx* ctx);
+
+/* Multi-GPU inside the library, one process per GPU.  No counterpart in the reference (single
+ * device).  nbody_comm_unique_id fills 128 bytes (an RCCL unique id) on ONE rank; the host hands
+ * them to the other ranks by its own means (a file, MPI, torch.distributed ...).  nbody_comm_init
+ * (collective: every rank calls it with the same id) attaches an RCCL communicator to the context;
+ * RCCL is loaded then, from the process if it already holds one.  The ranks' contexts either have
+ * shard ranges that tile [0, n_bodies) in rank order, or all hold every body (no shard range).
+ * With a communicator nbody_step_allpairs and nbody_step_bh are complete steps, nsteps of them,
+ * enqueued on the context's stream with their collectives:
+ *   nbody_step_allpairs  own targets' forces and integration, then every rank's positions gathered
+ *                        in place; for the PLUMMER law from N = 65,536 the pair kernel's work is
+ *                        dealt over the ranks (nbody_allpairs_partial), the contributions
+ *                        all-reduced, own targets integrated, positions gathered
+ *   nbody_step_bh        (contexts without a shard range) octree build on every rank, traversal
+ *                        of this rank's run [n k / world, n (k + 1) / world) of the sorted order,
+ *                        accelerations gathered by rank, all bodies integrated on every rank
+ * nbody_destroy releases the communicator. */
+int nbody_comm_unique_id(void* id_out128);
+int nbody_comm_init(nbody_ctx* ctx, const void* unique_id128, int rank, int world);
 
 /* Forces only (no integration, no swap), for parity checks against src/nbody.wgsl:50-116 and
  * src/nbodybh.wgsl:63-161.  host_acc16_out is f32[N][4]; only this context's targets are written. */

@@ -42,7 +42,8 @@ class NBodyCounters(C.Structure):
         ("bh_wave_node_visits", C.c_uint64),
         ("octree_nodes", C.c_uint64),
         ("bh_max_stack", C.c_uint64),
-        ("reserved", C.c_uint64 * 7),
+        ("allpairs_path", C.c_uint64),
+        ("reserved", C.c_uint64 * 6),
     ]
 
 
@@ -63,6 +64,8 @@ SYMBOLS = {
     "nbody_integrate_partial": (C.c_int, [_P]),
     "nbody_bh_forces_ranked": (C.c_int, [_P, C.c_uint64, C.c_uint64]),
     "nbody_integrate_ranked": (C.c_int, [_P]),
+    "nbody_comm_unique_id": (C.c_int, [_P]),
+    "nbody_comm_init": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "nbody_accel_allpairs": (C.c_int, [_P, _P]),
     "nbody_accel_allpairs_noalloc": (C.c_int, [_P, _P, C.c_uint64, C.c_int, C.c_float, C.c_float, _P, _P]),
     "nbody_accel_bh": (C.c_int, [_P, _P]),

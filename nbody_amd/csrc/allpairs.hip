@@ -572,10 +572,24 @@ int nb_allpairs_diag(nbody_ctx* ctx, const float4* posm_in, float4* diag_out, in
     return NBODY_OK;
 }
 
+// True when the pair kernel's scratch exists already or fits in half of the free device memory.
+static bool sym_scratch_fits(nbody_ctx* ctx, uint32_t seg, int tpl, uint64_t* need_out) {
+    const uint64_t need = nb_sym_scratch_bytes(ctx->n, seg, 256u * tpl);
+    if (need_out) *need_out = need;
+    if (ctx->sym != nullptr) return true;
+    size_t free_b = 0, total_b = 0;
+    return hipMemGetInfo(&free_b, &total_b) == hipSuccess && need < free_b / 2;
+}
+
 // One part's share of the pair tiles of ALL bodies (PLUMMER): acc_tmp[j] for every j.
 int nb_allpairs_partial(nbody_ctx* ctx, uint32_t part, uint32_t nparts) {
     const int tpl = sym_tpl();
-    return nb_allpairs_forces_sym(ctx, ctx->posm[ctx->cur], ctx->acc_tmp, sym_seg_tiles(ctx, tpl), tpl, part, nparts);
+    const uint32_t seg = sym_seg_tiles(ctx, tpl);
+    uint64_t need = 0;
+    if (!sym_scratch_fits(ctx, seg, tpl, &need))
+        return nb_fail(ctx, NBODY_ERR_NOMEM, "nbody_allpairs_partial: the pair kernel needs " + std::to_string(need >> 20) +
+                                                 " MiB of partial rows, more than half of the free device memory");
+    return nb_allpairs_forces_sym(ctx, ctx->posm[ctx->cur], ctx->acc_tmp, seg, tpl, part, nparts);
 }
 
 // Forces on this context's targets from all n sources in posm_in; acc_out[i] for i in the range.
@@ -589,11 +603,8 @@ int nb_allpairs_forces(nbody_ctx* ctx, const float4* posm_in, const float4* vel_
         // one evaluation per unordered pair; needs (superblocks x n / 2) x 16 B of partial rows
         const int tpl = sym_tpl();
         const uint32_t seg = sym_seg_tiles(ctx, tpl);
-        size_t free_b = 0, total_b = 0;
-        const uint64_t need = nb_sym_scratch_bytes(ctx->n, seg, 256u * tpl);
-        const bool have = ctx->sym != nullptr;
-        if (have || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need < free_b / 2))
-            return nb_allpairs_forces_sym(ctx, posm_in, acc_out, seg, tpl, 0, 1);
+        if (sym_scratch_fits(ctx, seg, tpl, nullptr)) return nb_allpairs_forces_sym(ctx, posm_in, acc_out, seg, tpl, 0, 1);
+        // otherwise the plain kernel below; nbody_counters().allpairs_path tells which one ran
     }
     const ApPlan pl = ap_plan(ctx->n, ctx->i_count, ctx->num_cus, ~0ull);
     if ((uint64_t)pl.slices > ctx->acc_part_slices) {
@@ -616,6 +627,7 @@ int nb_allpairs_forces(nbody_ctx* ctx, const float4* posm_in, const float4* vel_
     NB_HIP(ctx, hipGetLastError());
     ctx->counters.interactions_allpairs +=
         (law == NBODY_LAW_CPU_R6) ? ctx->i_count * (ctx->n - 1) : ctx->i_count * ctx->n;
+    ctx->counters.allpairs_path = 1;
     return NBODY_OK;
 }
 

@@ -263,13 +263,10 @@ struct SymPlan {
     float4* diag = nullptr;
 };
 
+static void sym_free(SymPlan* P);
+
 void nb_sym_destroy(nbody_ctx* ctx) {
-    SymPlan* P = ctx->sym;
-    if (!P) return;
-    void* ptrs[] = {P->items, P->rowoff, P->item_start, P->seg_of, P->part_j, P->part_i, P->diag};
-    for (void* p : ptrs)
-        if (p) hipFree(p);
-    delete P;
+    sym_free(ctx->sym);
     ctx->sym = nullptr;
 }
 
@@ -307,11 +304,20 @@ uint64_t nb_sym_scratch_bytes(uint64_t n, uint32_t seg_tiles, uint32_t SB) {
     return (rows + items * SB + (SB / NB_DIAG_TILE) * n) * sizeof(float4);
 }
 
+static void sym_free(SymPlan* P) {
+    if (!P) return;
+    void* ptrs[] = {P->items, P->rowoff, P->item_start, P->seg_of, P->part_j, P->part_i, P->diag};
+    for (void* p : ptrs)
+        if (p) hipFree(p);
+    delete P;
+}
+
+// The plan is attached to the context only once every buffer of it exists: a failed allocation
+// leaves the context without a plan, so the next call plans (and fails, or succeeds) afresh.
 static int sym_prepare(nbody_ctx* ctx, uint32_t seg_tiles, uint32_t SB) {
     if (ctx->sym && ctx->sym->n == ctx->n && ctx->sym->sb == SB && ctx->sym->seg == seg_tiles) return NBODY_OK;
     nb_sym_destroy(ctx);
     SymPlan* P = new SymPlan;
-    ctx->sym = P;
     P->n = ctx->n;
     P->sb = SB;
     P->seg = seg_tiles;
@@ -335,18 +341,30 @@ static int sym_prepare(nbody_ctx* ctx, uint32_t seg_tiles, uint32_t SB) {
     rowoff[nsb] = rows;
     item_start[nsb] = (uint32_t)items.size();
     P->n_items = (uint32_t)items.size();
-    NB_HIP(ctx, hipMalloc(&P->items, std::max<size_t>(1, items.size()) * sizeof(SymItem)));
-    NB_HIP(ctx, hipMalloc(&P->rowoff, rowoff.size() * sizeof(unsigned long long)));
-    NB_HIP(ctx, hipMalloc(&P->item_start, item_start.size() * sizeof(uint32_t)));
-    NB_HIP(ctx, hipMalloc(&P->seg_of, seg_of.size() * sizeof(uint32_t)));
-    NB_HIP(ctx, hipMemcpyAsync(P->seg_of, seg_of.data(), seg_of.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    NB_HIP(ctx, hipMalloc(&P->part_j, std::max<unsigned long long>(1, rows) * sizeof(float4)));
-    NB_HIP(ctx, hipMalloc(&P->part_i, std::max<size_t>(1, items.size()) * SB * sizeof(float4)));
-    NB_HIP(ctx, hipMalloc(&P->diag, (size_t)(SB / NB_DIAG_TILE) * n * sizeof(float4)));
-    NB_HIP(ctx, hipMemcpyAsync(P->items, items.data(), items.size() * sizeof(SymItem), hipMemcpyHostToDevice, ctx->stream));
-    NB_HIP(ctx, hipMemcpyAsync(P->rowoff, rowoff.data(), rowoff.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, ctx->stream));
-    NB_HIP(ctx, hipMemcpyAsync(P->item_start, item_start.data(), item_start.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    NB_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the host vectors go out of scope
+    hipError_t e = hipMalloc(&P->items, std::max<size_t>(1, items.size()) * sizeof(SymItem));
+    if (e == hipSuccess) e = hipMalloc(&P->rowoff, rowoff.size() * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(&P->item_start, item_start.size() * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&P->seg_of, seg_of.size() * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&P->part_j, std::max<unsigned long long>(1, rows) * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc(&P->part_i, std::max<size_t>(1, items.size()) * SB * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc(&P->diag, (size_t)(SB / NB_DIAG_TILE) * n * sizeof(float4));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        sym_free(P);
+        return nb_fail(ctx, NBODY_ERR_NOMEM, std::string("pair kernel scratch: ") + hipGetErrorString(e));
+    }
+    e = hipMemcpyAsync(P->seg_of, seg_of.data(), seg_of.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(P->items, items.data(), items.size() * sizeof(SymItem), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(P->rowoff, rowoff.data(), rowoff.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(P->item_start, item_start.data(), item_start.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the host vectors go out of scope
+    if (e != hipSuccess) {
+        sym_free(P);
+        return nb_fail(ctx, NBODY_ERR_HIP, std::string("pair kernel plan upload: ") + hipGetErrorString(e));
+    }
+    ctx->sym = P;
     return NBODY_OK;
 }
 
@@ -389,5 +407,6 @@ int nb_allpairs_forces_sym(nbody_ctx* ctx, const float4* posm_in, float4* acc_ou
                            (int)ctx->i_begin, (int)(ctx->i_begin + ctx->i_count), (int)(SB / NB_DIAG_TILE), acc_out);
     NB_HIP(ctx, hipGetLastError());
     ctx->counters.interactions_allpairs += ctx->n * ctx->n / nparts;
+    ctx->counters.allpairs_path = 2;
     return NBODY_OK;
 }

@@ -41,24 +41,38 @@ int set_device(nbody_ctx* ctx) {
     return NBODY_OK;
 }
 
+// Positions pass through a buffer of their own (never through NBODY_BUF_ACC_PARTIAL, whose
+// contents a host may be exchanging between nbody_allpairs_partial / nbody_bh_forces_ranked and
+// the integrate call that follows).
+int ensure_stage(nbody_ctx* ctx) {
+    if (ctx->stage) return NBODY_OK;
+    if (hipMalloc(&ctx->stage, ctx->n * sizeof(float4)) != hipSuccess) {
+        ctx->stage = nullptr;
+        (void)hipGetLastError();
+        return nb_fail(ctx, NBODY_ERR_NOMEM, "position staging buffer: out of device memory");
+    }
+    return NBODY_OK;
+}
+
 int upload_set(nbody_ctx* ctx, int s, const float* masses, const float* pos16, const float* vel16, const float* acc16,
                bool need_pos) {
     const size_t b16 = ctx->n * sizeof(float4);
+    if (int r = ensure_stage(ctx)) return r;
     if (pos16) {
-        // stage through acc_tmp: pos16 -> device, then pack the mass into the pad lane
-        NB_HIP(ctx, hipMemcpyAsync(ctx->acc_tmp, pos16, b16, hipMemcpyHostToDevice, ctx->stream));
+        // pos16 -> device, then pack the mass into the pad lane
+        NB_HIP(ctx, hipMemcpyAsync(ctx->stage, pos16, b16, hipMemcpyHostToDevice, ctx->stream));
         if (masses) NB_HIP(ctx, hipMemcpyAsync(ctx->masses, masses, ctx->n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
         unsigned nb = (unsigned)((ctx->n + 255) / 256);
-        hipLaunchKernelGGL(k_pack_posm, dim3(nb), dim3(256), 0, ctx->stream, ctx->acc_tmp, ctx->masses, ctx->posm[s],
+        hipLaunchKernelGGL(k_pack_posm, dim3(nb), dim3(256), 0, ctx->stream, ctx->stage, ctx->masses, ctx->posm[s],
                            (int)ctx->n);
         NB_HIP(ctx, hipGetLastError());
     } else if (need_pos) {
         return nb_fail(ctx, NBODY_ERR_INVALID, "positions are required");
     } else {
         // zero positions, masses kept in the pad lane
-        NB_HIP(ctx, hipMemsetAsync(ctx->acc_tmp, 0, b16, ctx->stream));
+        NB_HIP(ctx, hipMemsetAsync(ctx->stage, 0, b16, ctx->stream));
         unsigned nb = (unsigned)((ctx->n + 255) / 256);
-        hipLaunchKernelGGL(k_pack_posm, dim3(nb), dim3(256), 0, ctx->stream, ctx->acc_tmp, ctx->masses, ctx->posm[s],
+        hipLaunchKernelGGL(k_pack_posm, dim3(nb), dim3(256), 0, ctx->stream, ctx->stage, ctx->masses, ctx->posm[s],
                            (int)ctx->n);
         NB_HIP(ctx, hipGetLastError());
     }
@@ -74,10 +88,11 @@ int upload_set(nbody_ctx* ctx, int s, const float* masses, const float* pos16, c
 int download_set(nbody_ctx* ctx, int s, float* pos16, float* vel16, float* acc16) {
     const size_t b16 = ctx->n * sizeof(float4);
     if (pos16) {
+        if (int r = ensure_stage(ctx)) return r;
         unsigned nb = (unsigned)((ctx->n + 255) / 256);
-        hipLaunchKernelGGL(k_strip_pad, dim3(nb), dim3(256), 0, ctx->stream, ctx->posm[s], ctx->acc_tmp, (int)ctx->n);
+        hipLaunchKernelGGL(k_strip_pad, dim3(nb), dim3(256), 0, ctx->stream, ctx->posm[s], ctx->stage, (int)ctx->n);
         NB_HIP(ctx, hipGetLastError());
-        NB_HIP(ctx, hipMemcpyAsync(pos16, ctx->acc_tmp, b16, hipMemcpyDeviceToHost, ctx->stream));
+        NB_HIP(ctx, hipMemcpyAsync(pos16, ctx->stage, b16, hipMemcpyDeviceToHost, ctx->stream));
     }
     if (vel16) NB_HIP(ctx, hipMemcpyAsync(vel16, ctx->vel[s], b16, hipMemcpyDeviceToHost, ctx->stream));
     if (acc16) NB_HIP(ctx, hipMemcpyAsync(acc16, ctx->acc[s], b16, hipMemcpyDeviceToHost, ctx->stream));
@@ -141,7 +156,7 @@ int nbody_create(nbody_ctx** out, const nbody_config* cfg) {
         return NBODY_ERR_INVALID;
     }
     uint64_t sc = cfg->shard_count ? cfg->shard_count : cfg->n_bodies - cfg->shard_begin;
-    if (cfg->shard_begin >= cfg->n_bodies || cfg->shard_begin + sc > cfg->n_bodies) {
+    if (cfg->shard_begin >= cfg->n_bodies || sc > cfg->n_bodies - cfg->shard_begin) {
         g_nbody_create_error = "nbody_create: shard range outside [0, n_bodies)";
         return NBODY_ERR_INVALID;
     }
@@ -208,6 +223,7 @@ void nbody_destroy(nbody_ctx* ctx) {
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     for (int which = 0; which < 3; ++which) nb_time_collect(ctx, which);
+    nb_comm_destroy(ctx);
     nb_tree_destroy(ctx);
     nb_sym_destroy(ctx);
     for (int s = 0; s < 2; ++s) {
@@ -216,6 +232,7 @@ void nbody_destroy(nbody_ctx* ctx) {
         if (ctx->acc[s]) hipFree(ctx->acc[s]);
     }
     if (ctx->acc_tmp) hipFree(ctx->acc_tmp);
+    if (ctx->stage) hipFree(ctx->stage);
     if (ctx->acc_part) hipFree(ctx->acc_part);
     if (ctx->acc_body) hipFree(ctx->acc_body);
     if (ctx->masses) hipFree(ctx->masses);
@@ -230,44 +247,92 @@ int nbody_upload(nbody_ctx* ctx, const float* host_masses, const float* host_pos
                  const float* host_acc16) {
     if (!ctx) return NBODY_ERR_INVALID;
     if (!host_masses || !host_pos16) return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_upload: masses and positions are required");
-    int r = set_device(ctx);
-    if (r) return r;
-    ctx->cur = 0;
-    ctx->leapfrog_started = false;
-    ctx->mass0 = host_masses[0];
-    ctx->uniform_mass = true;
-    for (uint64_t i = 1; i < ctx->n && ctx->uniform_mass; ++i) ctx->uniform_mass = host_masses[i] == ctx->mass0;
-    r = upload_set(ctx, 0, host_masses, host_pos16, host_vel16, host_acc16, true);
-    if (r) return r;
-    // second set: zeros (src/nbody_cpu.rs:58-60), mass kept in the pad lane
-    r = upload_set(ctx, 1, nullptr, nullptr, nullptr, nullptr, false);
-    if (r) return r;
-    ctx->uploaded = true;
-    return NBODY_OK;
+    return guarded(ctx, [&]() -> int {
+        int r = set_device(ctx);
+        if (r) return r;
+        ctx->cur = 0;
+        ctx->leapfrog_started = false;
+        ctx->pending_forces = 0;
+        ctx->mass0 = host_masses[0];
+        ctx->uniform_mass = true;
+        for (uint64_t i = 1; i < ctx->n && ctx->uniform_mass; ++i) ctx->uniform_mass = host_masses[i] == ctx->mass0;
+        r = upload_set(ctx, 0, host_masses, host_pos16, host_vel16, host_acc16, true);
+        if (r) return r;
+        // second set: zeros (src/nbody_cpu.rs:58-60), mass kept in the pad lane
+        r = upload_set(ctx, 1, nullptr, nullptr, nullptr, nullptr, false);
+        if (r) return r;
+        ctx->uploaded = true;
+        return NBODY_OK;
+    });
 }
 
 int nbody_upload_alt(nbody_ctx* ctx, const float* host_pos16, const float* host_vel16, const float* host_acc16) {
     if (!ctx) return NBODY_ERR_INVALID;
     if (!ctx->uploaded) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_upload_alt: call nbody_upload first");
-    int r = set_device(ctx);
-    if (r) return r;
-    return upload_set(ctx, ctx->cur ^ 1, nullptr, host_pos16, host_vel16, host_acc16, false);
+    return guarded(ctx, [&]() -> int {
+        int r = set_device(ctx);
+        if (r) return r;
+        return upload_set(ctx, ctx->cur ^ 1, nullptr, host_pos16, host_vel16, host_acc16, false);
+    });
 }
+
+namespace {
+
+const char* bh_refusal(const nbody_ctx* ctx) {
+    if (ctx->cfg.law == NBODY_LAW_CPU_R6) return "the Barnes-Hut path uses the WGSL laws (src/nbodybh.wgsl), not CPU_R6";
+    if (ctx->cfg.integrator == NBODY_INT_CPU_EULER_XBUF)
+        return "the Barnes-Hut path integrates as src/nbodybh.wgsl:163-169 (or leapfrog), not with the cross-buffer Euler update";
+    return nullptr;
+}
+
+// The pair kernel dealt over the ranks applies where it does on one GPU: a symmetric law and
+// enough bodies; every rank evaluates the same condition.
+bool pair_sharded(const nbody_ctx* ctx) {
+    return ctx->cfg.law == NBODY_LAW_PLUMMER && ctx->cfg.integrator != NBODY_INT_CPU_EULER_XBUF && ctx->n >= 65536;
+}
+
+int ranked_integrate(nbody_ctx* ctx) {
+    if (!ctx->acc_body && hipMalloc(&ctx->acc_body, ctx->n * sizeof(float4)) != hipSuccess) {
+        ctx->acc_body = nullptr;
+        (void)hipGetLastError();
+        return nb_fail(ctx, NBODY_ERR_NOMEM, "accelerations in body order: out of device memory");
+    }
+    int r = nb_tree_unrank(ctx, ctx->acc_tmp, ctx->acc_body);
+    if (r) return r;
+    r = nb_integrate_clamped(ctx, ctx->acc_body);
+    if (r) return r;
+    ctx->counters.steps_bh += 1;
+    return NBODY_OK;
+}
+
+}  // namespace
 
 int nbody_step_allpairs(nbody_ctx* ctx, int nsteps) {
     if (!ctx) return NBODY_ERR_INVALID;
     if (!ctx->uploaded) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_step_allpairs: no bodies uploaded");
     if (nsteps < 0) return nb_fail(ctx, NBODY_ERR_INVALID, "nsteps < 0");
-    if (ctx->i_count < ctx->n && nsteps > 1)
-        return nb_fail(ctx, NBODY_ERR_INVALID, "a sharded context steps once per call: all-gather NBODY_BUF_POSM between steps");
-    int r = set_device(ctx);
-    if (r) return r;
+    if (ctx->i_count < ctx->n && nsteps > 1 && !ctx->comm)
+        return nb_fail(ctx, NBODY_ERR_INVALID,
+                       "a sharded context without a communicator steps once per call: all-gather NBODY_BUF_POSM between steps");
     return guarded(ctx, [&]() -> int {
+        int rc = set_device(ctx);
+        if (rc) return rc;
+        ctx->pending_forces = 0;
         for (int s = 0; s < nsteps; ++s) {
-            int rc = nb_allpairs_forces(ctx, ctx->posm[ctx->cur], ctx->vel[ctx->cur], ctx->acc_tmp);
+            if (ctx->comm && pair_sharded(ctx)) {
+                rc = nb_allpairs_partial(ctx, (uint32_t)nb_comm_rank(ctx), (uint32_t)nb_comm_world(ctx));
+                if (rc) return rc;
+                rc = nb_comm_allreduce_partial(ctx);
+            } else {
+                rc = nb_allpairs_forces(ctx, ctx->posm[ctx->cur], ctx->vel[ctx->cur], ctx->acc_tmp);
+            }
             if (rc) return rc;
             rc = nb_integrate(ctx, ctx->acc_tmp);
             if (rc) return rc;
+            if (ctx->comm) {
+                rc = nb_comm_gather_positions(ctx);
+                if (rc) return rc;
+            }
             ctx->counters.steps_allpairs += 1;
         }
         return NBODY_OK;
@@ -281,62 +346,92 @@ int nbody_allpairs_partial(nbody_ctx* ctx, uint32_t part, uint32_t nparts) {
         return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_allpairs_partial: only the PLUMMER law (symmetric in the pair), not the cross-buffer integrator");
     if (nparts == 0 || part >= nparts) return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_allpairs_partial: part >= nparts");
     if (ctx->n < 4097) return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_allpairs_partial: needs at least two superblocks of bodies (N > 4096)");
-    int r = set_device(ctx);
-    if (r) return r;
-    return guarded(ctx, [&]() -> int { return nb_allpairs_partial(ctx, part, nparts); });
+    return guarded(ctx, [&]() -> int {
+        int r = set_device(ctx);
+        if (r) return r;
+        ctx->pending_forces = 0;
+        r = nb_allpairs_partial(ctx, part, nparts);
+        if (r) return r;
+        ctx->pending_forces = 1;
+        return NBODY_OK;
+    });
 }
 
 int nbody_integrate_partial(nbody_ctx* ctx) {
     if (!ctx) return NBODY_ERR_INVALID;
     if (!ctx->uploaded) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_integrate_partial: no bodies uploaded");
-    int r = set_device(ctx);
-    if (r) return r;
-    r = nb_integrate(ctx, ctx->acc_tmp);
-    if (r) return r;
-    ctx->counters.steps_allpairs += 1;
-    return NBODY_OK;
+    if (ctx->pending_forces != 1)
+        return nb_fail(ctx, NBODY_ERR_STATE,
+                       "nbody_integrate_partial: NBODY_BUF_ACC_PARTIAL does not hold the forces of nbody_allpairs_partial (another call has used the buffer since)");
+    return guarded(ctx, [&]() -> int {
+        int r = set_device(ctx);
+        if (r) return r;
+        ctx->pending_forces = 0;
+        r = nb_integrate(ctx, ctx->acc_tmp);
+        if (r) return r;
+        ctx->counters.steps_allpairs += 1;
+        return NBODY_OK;
+    });
 }
 
 int nbody_step_bh(nbody_ctx* ctx, int nsteps) {
     if (!ctx) return NBODY_ERR_INVALID;
     if (!ctx->uploaded) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_step_bh: no bodies uploaded");
     if (nsteps < 0) return nb_fail(ctx, NBODY_ERR_INVALID, "nsteps < 0");
-    if (ctx->cfg.law == NBODY_LAW_CPU_R6)
-        return nb_fail(ctx, NBODY_ERR_INVALID, "the Barnes-Hut path uses the WGSL laws (src/nbodybh.wgsl), not CPU_R6");
-    if (ctx->cfg.integrator == NBODY_INT_CPU_EULER_XBUF)
-        return nb_fail(ctx, NBODY_ERR_INVALID, "the Barnes-Hut path integrates as src/nbodybh.wgsl:163-169 (or leapfrog), not with the cross-buffer Euler update");
+    if (const char* why = bh_refusal(ctx)) return nb_fail(ctx, NBODY_ERR_INVALID, why);
+    if (ctx->comm && ctx->i_count < ctx->n)
+        return nb_fail(ctx, NBODY_ERR_INVALID,
+                       "nbody_step_bh with a communicator needs a context without a shard range (every rank holds all bodies)");
     if (ctx->i_count < ctx->n && nsteps > 1)
         return nb_fail(ctx, NBODY_ERR_INVALID, "a sharded context steps once per call: all-gather NBODY_BUF_POSM between steps");
-    int r = set_device(ctx);
-    if (r) return r;
-    for (int s = 0; s < nsteps; ++s) {
-        r = nb_tree_build(ctx, ctx->posm[ctx->cur]);
+    return guarded(ctx, [&]() -> int {
+        int r = set_device(ctx);
         if (r) return r;
-        r = nb_tree_walk(ctx, ctx->posm[ctx->cur], ctx->vel[ctx->cur], ctx->acc_tmp);
-        if (r) return r;
-        r = nb_integrate_clamped(ctx, ctx->acc_tmp);
-        if (r) return r;
-        ctx->counters.steps_bh += 1;
-    }
-    return NBODY_OK;
+        ctx->pending_forces = 0;
+        for (int s = 0; s < nsteps; ++s) {
+            r = nb_tree_build(ctx, ctx->posm[ctx->cur]);
+            if (r) return r;
+            if (ctx->comm) {
+                // this rank's run of the sorted order, the runs gathered by rank, all bodies integrated
+                uint64_t rb = 0, rc = 0;
+                nb_comm_run(ctx, nb_comm_rank(ctx), &rb, &rc);
+                r = nb_tree_walk_ranked(ctx, ctx->posm[ctx->cur], ctx->vel[ctx->cur], ctx->acc_tmp, rb, rc);
+                if (r) return r;
+                r = nb_comm_gather_ranked(ctx);
+                if (r) return r;
+                r = ranked_integrate(ctx);
+                if (r) return r;
+                continue;
+            }
+            r = nb_tree_walk(ctx, ctx->posm[ctx->cur], ctx->vel[ctx->cur], ctx->acc_tmp);
+            if (r) return r;
+            r = nb_integrate_clamped(ctx, ctx->acc_tmp);
+            if (r) return r;
+            ctx->counters.steps_bh += 1;
+        }
+        return NBODY_OK;
+    });
 }
 
 int nbody_bh_forces_ranked(nbody_ctx* ctx, uint64_t rank_begin, uint64_t rank_count) {
     if (!ctx) return NBODY_ERR_INVALID;
     if (!ctx->uploaded) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_bh_forces_ranked: no bodies uploaded");
-    if (ctx->cfg.law == NBODY_LAW_CPU_R6)
-        return nb_fail(ctx, NBODY_ERR_INVALID, "the Barnes-Hut path uses the WGSL laws (src/nbodybh.wgsl), not CPU_R6");
-    if (ctx->cfg.integrator == NBODY_INT_CPU_EULER_XBUF)
-        return nb_fail(ctx, NBODY_ERR_INVALID, "the Barnes-Hut path integrates as src/nbodybh.wgsl:163-169 (or leapfrog), not with the cross-buffer Euler update");
+    if (const char* why = bh_refusal(ctx)) return nb_fail(ctx, NBODY_ERR_INVALID, why);
     if (ctx->i_count != ctx->n)
         return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_bh_forces_ranked: the context must hold all bodies (no shard range)");
     if (rank_begin > ctx->n || rank_count > ctx->n - rank_begin)
         return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_bh_forces_ranked: rank range outside the bodies");
-    int r = set_device(ctx);
-    if (r) return r;
-    r = nb_tree_build(ctx, ctx->posm[ctx->cur]);
-    if (r) return r;
-    return nb_tree_walk_ranked(ctx, ctx->posm[ctx->cur], ctx->vel[ctx->cur], ctx->acc_tmp, rank_begin, rank_count);
+    return guarded(ctx, [&]() -> int {
+        int r = set_device(ctx);
+        if (r) return r;
+        ctx->pending_forces = 0;
+        r = nb_tree_build(ctx, ctx->posm[ctx->cur]);
+        if (r) return r;
+        r = nb_tree_walk_ranked(ctx, ctx->posm[ctx->cur], ctx->vel[ctx->cur], ctx->acc_tmp, rank_begin, rank_count);
+        if (r) return r;
+        ctx->pending_forces = 2;
+        return NBODY_OK;
+    });
 }
 
 int nbody_integrate_ranked(nbody_ctx* ctx) {
@@ -344,30 +439,32 @@ int nbody_integrate_ranked(nbody_ctx* ctx) {
     if (!ctx->uploaded) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_integrate_ranked: no bodies uploaded");
     if (ctx->i_count != ctx->n)
         return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_integrate_ranked: the context must hold all bodies (no shard range)");
-    if (ctx->cfg.integrator == NBODY_INT_CPU_EULER_XBUF)
-        return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_integrate_ranked: the Barnes-Hut path integrates as src/nbodybh.wgsl:163-169 (or leapfrog), not with the cross-buffer Euler update");
-    int r = set_device(ctx);
-    if (r) return r;
-    if (!ctx->acc_body) NB_HIP(ctx, hipMalloc(&ctx->acc_body, ctx->n * sizeof(float4)));
-    r = nb_tree_unrank(ctx, ctx->acc_tmp, ctx->acc_body);
-    if (r) return r;
-    r = nb_integrate_clamped(ctx, ctx->acc_body);
-    if (r) return r;
-    ctx->counters.steps_bh += 1;
-    return NBODY_OK;
+    if (const char* why = bh_refusal(ctx)) return nb_fail(ctx, NBODY_ERR_INVALID, why);
+    if (ctx->pending_forces != 2)
+        return nb_fail(ctx, NBODY_ERR_STATE,
+                       "nbody_integrate_ranked: NBODY_BUF_ACC_PARTIAL does not hold the forces of nbody_bh_forces_ranked (another call has used the buffer since)");
+    return guarded(ctx, [&]() -> int {
+        int r = set_device(ctx);
+        if (r) return r;
+        ctx->pending_forces = 0;
+        return ranked_integrate(ctx);
+    });
 }
 
 int nbody_accel_allpairs(nbody_ctx* ctx, float* host_acc16_out) {
     if (!ctx || !host_acc16_out) return NBODY_ERR_INVALID;
     if (!ctx->uploaded) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_accel_allpairs: no bodies uploaded");
-    int r = set_device(ctx);
-    if (r) return r;
-    r = guarded(ctx, [&]() -> int { return nb_allpairs_forces(ctx, ctx->posm[ctx->cur], ctx->vel[ctx->cur], ctx->acc_tmp); });
-    if (r) return r;
-    NB_HIP(ctx, hipMemcpyAsync(host_acc16_out + 4 * ctx->i_begin, ctx->acc_tmp + ctx->i_begin,
-                               ctx->i_count * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
-    NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return NBODY_OK;
+    return guarded(ctx, [&]() -> int {
+        int r = set_device(ctx);
+        if (r) return r;
+        ctx->pending_forces = 0;
+        r = nb_allpairs_forces(ctx, ctx->posm[ctx->cur], ctx->vel[ctx->cur], ctx->acc_tmp);
+        if (r) return r;
+        NB_HIP(ctx, hipMemcpyAsync(host_acc16_out + 4 * ctx->i_begin, ctx->acc_tmp + ctx->i_begin,
+                                   ctx->i_count * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+        NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return NBODY_OK;
+    });
 }
 
 int nbody_accel_bh(nbody_ctx* ctx, float* host_acc16_out) {
@@ -375,87 +472,108 @@ int nbody_accel_bh(nbody_ctx* ctx, float* host_acc16_out) {
     if (!ctx->uploaded) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_accel_bh: no bodies uploaded");
     if (ctx->cfg.law == NBODY_LAW_CPU_R6)
         return nb_fail(ctx, NBODY_ERR_INVALID, "the Barnes-Hut path uses the WGSL laws (src/nbodybh.wgsl), not CPU_R6");
-    int r = set_device(ctx);
-    if (r) return r;
-    r = nb_tree_walk(ctx, ctx->posm[ctx->cur], ctx->vel[ctx->cur], ctx->acc_tmp);
-    if (r) return r;
-    NB_HIP(ctx, hipMemcpyAsync(host_acc16_out + 4 * ctx->i_begin, ctx->acc_tmp + ctx->i_begin,
-                               ctx->i_count * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
-    NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return nb_tree_check(ctx);
+    return guarded(ctx, [&]() -> int {
+        int r = set_device(ctx);
+        if (r) return r;
+        ctx->pending_forces = 0;
+        r = nb_tree_walk(ctx, ctx->posm[ctx->cur], ctx->vel[ctx->cur], ctx->acc_tmp);
+        if (r) return r;
+        NB_HIP(ctx, hipMemcpyAsync(host_acc16_out + 4 * ctx->i_begin, ctx->acc_tmp + ctx->i_begin,
+                                   ctx->i_count * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+        NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return nb_tree_check(ctx);
+    });
 }
 
 int nbody_build_octree(nbody_ctx* ctx) {
     if (!ctx) return NBODY_ERR_INVALID;
     if (!ctx->uploaded) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_build_octree: no bodies uploaded");
-    int r = set_device(ctx);
-    if (r) return r;
-    return nb_tree_build(ctx, ctx->posm[ctx->cur]);
+    return guarded(ctx, [&]() -> int {
+        int r = set_device(ctx);
+        if (r) return r;
+        return nb_tree_build(ctx, ctx->posm[ctx->cur]);
+    });
 }
 
 int nbody_download_octree(nbody_ctx* ctx, nbody_octree_node* host_nodes, uint64_t cap_nodes, uint64_t* n_nodes) {
     if (!ctx) return NBODY_ERR_INVALID;
-    int r = set_device(ctx);
-    if (r) return r;
-    return nb_tree_download(ctx, host_nodes, cap_nodes, n_nodes);
+    return guarded(ctx, [&]() -> int {
+        int r = set_device(ctx);
+        if (r) return r;
+        return nb_tree_download(ctx, host_nodes, cap_nodes, n_nodes);
+    });
 }
 
 int nbody_upload_octree(nbody_ctx* ctx, const nbody_octree_node* host_nodes, uint64_t n_nodes) {
     if (!ctx || !host_nodes || n_nodes == 0) return ctx ? nb_fail(ctx, NBODY_ERR_INVALID, "nbody_upload_octree: empty tree") : NBODY_ERR_INVALID;
-    int r = set_device(ctx);
-    if (r) return r;
-    return guarded(ctx, [&]() -> int { return nb_tree_upload(ctx, host_nodes, n_nodes); });
+    return guarded(ctx, [&]() -> int {
+        int r = set_device(ctx);
+        if (r) return r;
+        return nb_tree_upload(ctx, host_nodes, n_nodes);
+    });
 }
 
 int nbody_morton_keys(nbody_ctx* ctx, uint64_t* host_keys, uint8_t* host_leaf_depth, uint32_t* host_order) {
     if (!ctx) return NBODY_ERR_INVALID;
-    int r = set_device(ctx);
-    if (r) return r;
-    return guarded(ctx, [&]() -> int { return nb_tree_keys(ctx, host_keys, host_leaf_depth, host_order); });
+    return guarded(ctx, [&]() -> int {
+        int r = set_device(ctx);
+        if (r) return r;
+        return nb_tree_keys(ctx, host_keys, host_leaf_depth, host_order);
+    });
 }
 
 int nbody_download(nbody_ctx* ctx, float* host_pos16, float* host_vel16, float* host_acc16) {
     if (!ctx) return NBODY_ERR_INVALID;
     if (!ctx->uploaded) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_download: no bodies uploaded");
-    int r = set_device(ctx);
-    if (r) return r;
-    r = download_set(ctx, ctx->cur, host_pos16, host_vel16, host_acc16);
-    if (r) return r;
-    return nb_tree_check(ctx);
+    return guarded(ctx, [&]() -> int {
+        int r = set_device(ctx);
+        if (r) return r;
+        r = download_set(ctx, ctx->cur, host_pos16, host_vel16, host_acc16);
+        if (r) return r;
+        return nb_tree_check(ctx);
+    });
 }
 
 int nbody_download_alt(nbody_ctx* ctx, float* host_pos16, float* host_vel16, float* host_acc16) {
     if (!ctx) return NBODY_ERR_INVALID;
     if (!ctx->uploaded) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_download_alt: no bodies uploaded");
-    int r = set_device(ctx);
-    if (r) return r;
-    return download_set(ctx, ctx->cur ^ 1, host_pos16, host_vel16, host_acc16);
+    return guarded(ctx, [&]() -> int {
+        int r = set_device(ctx);
+        if (r) return r;
+        return download_set(ctx, ctx->cur ^ 1, host_pos16, host_vel16, host_acc16);
+    });
 }
 
 int nbody_sync(nbody_ctx* ctx) {
     if (!ctx) return NBODY_ERR_INVALID;
-    int r = set_device(ctx);
-    if (r) return r;
-    NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return nb_tree_check(ctx);
+    return guarded(ctx, [&]() -> int {
+        int r = set_device(ctx);
+        if (r) return r;
+        NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return nb_tree_check(ctx);
+    });
 }
 
 int nbody_energy(nbody_ctx* ctx, double* kinetic, double* potential) {
     if (!ctx) return NBODY_ERR_INVALID;
     if (!ctx->uploaded) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_energy: no bodies uploaded");
     if (ctx->i_count < ctx->n) return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_energy needs an unsharded context");
-    int r = set_device(ctx);
-    if (r) return r;
-    return nb_energy(ctx, kinetic, potential);
+    return guarded(ctx, [&]() -> int {
+        int r = set_device(ctx);
+        if (r) return r;
+        return nb_energy(ctx, kinetic, potential);
+    });
 }
 
 int nbody_counters(nbody_ctx* ctx, nbody_counters_t* out) {
     if (!ctx || !out) return NBODY_ERR_INVALID;
-    int r = set_device(ctx);
-    if (r) return r;
-    NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    *out = ctx->counters;
-    return NBODY_OK;
+    return guarded(ctx, [&]() -> int {
+        int r = set_device(ctx);
+        if (r) return r;
+        NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        *out = ctx->counters;
+        return NBODY_OK;
+    });
 }
 
 int nbody_counters_reset(nbody_ctx* ctx) {
@@ -477,7 +595,13 @@ int nbody_device_buffer(nbody_ctx* ctx, int which, void** dev_ptr, size_t* bytes
         case NBODY_BUF_POSM: *dev_ptr = ctx->posm[ctx->cur]; if (bytes) *bytes = b16; return NBODY_OK;
         case NBODY_BUF_VEL: *dev_ptr = ctx->vel[ctx->cur]; if (bytes) *bytes = b16; return NBODY_OK;
         case NBODY_BUF_ACC: *dev_ptr = ctx->acc[ctx->cur]; if (bytes) *bytes = b16; return NBODY_OK;
-        case NBODY_BUF_OCTREE: return nb_tree_device_nodes(ctx, dev_ptr, bytes);
+        case NBODY_BUF_OCTREE:
+            // (the export allocates and launches: on the context's device)
+            return guarded(ctx, [&]() -> int {
+                int r = set_device(ctx);
+                if (r) return r;
+                return nb_tree_device_nodes(ctx, dev_ptr, bytes);
+            });
         case NBODY_BUF_ACC_PARTIAL: *dev_ptr = ctx->acc_tmp; if (bytes) *bytes = b16; return NBODY_OK;
         default: return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_device_buffer: unknown buffer");
     }
@@ -485,16 +609,18 @@ int nbody_device_buffer(nbody_ctx* ctx, int which, void** dev_ptr, size_t* bytes
 
 int nbody_read_buffer(nbody_ctx* ctx, int which, void* host_dst, size_t bytes) {
     if (!ctx || !host_dst) return NBODY_ERR_INVALID;
-    int r = set_device(ctx);
-    if (r) return r;
-    void* dev = nullptr;
-    size_t have = 0;
-    r = nbody_device_buffer(ctx, which, &dev, &have);
-    if (r) return r;
-    if (bytes > have) return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_read_buffer: more bytes requested than the buffer holds");
-    NB_HIP(ctx, hipMemcpyAsync(host_dst, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return NBODY_OK;
+    return guarded(ctx, [&]() -> int {
+        int r = set_device(ctx);
+        if (r) return r;
+        void* dev = nullptr;
+        size_t have = 0;
+        r = nbody_device_buffer(ctx, which, &dev, &have);
+        if (r) return r;
+        if (bytes > have) return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_read_buffer: more bytes requested than the buffer holds");
+        NB_HIP(ctx, hipMemcpyAsync(host_dst, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return NBODY_OK;
+    });
 }
 
 void* nbody_stream(nbody_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
@@ -508,15 +634,38 @@ int nbody_set_kernel_timing(nbody_ctx* ctx, int on) {
 int nbody_kernel_time(nbody_ctx* ctx, int which, double* avg_ms, uint64_t* launches) {
     if (!ctx) return NBODY_ERR_INVALID;
     if (which < 0 || which > 2) return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_kernel_time: which must be 0, 1 or 2");
-    int r = set_device(ctx);
-    if (r) return r;
-    r = nb_time_collect(ctx, which);
-    if (r) return r;
-    if (launches) *launches = ctx->time_launches[which];
-    if (avg_ms) *avg_ms = ctx->time_launches[which] ? ctx->time_acc_ms[which] / (double)ctx->time_launches[which] : 0.0;
-    ctx->time_acc_ms[which] = 0;
-    ctx->time_launches[which] = 0;
-    return NBODY_OK;
+    return guarded(ctx, [&]() -> int {
+        int r = set_device(ctx);
+        if (r) return r;
+        r = nb_time_collect(ctx, which);
+        if (r) return r;
+        if (launches) *launches = ctx->time_launches[which];
+        if (avg_ms) *avg_ms = ctx->time_launches[which] ? ctx->time_acc_ms[which] / (double)ctx->time_launches[which] : 0.0;
+        ctx->time_acc_ms[which] = 0;
+        ctx->time_launches[which] = 0;
+        return NBODY_OK;
+    });
+}
+
+int nbody_comm_unique_id(void* id_out128) {
+    if (!id_out128) return NBODY_ERR_INVALID;
+    try {
+        int r = nb_comm_unique_id(id_out128);
+        if (r) g_nbody_create_error = "nbody_comm_unique_id: librccl could not be loaded or ncclGetUniqueId failed";
+        return r;
+    } catch (...) {
+        return NBODY_ERR_NOMEM;
+    }
+}
+
+int nbody_comm_init(nbody_ctx* ctx, const void* unique_id128, int rank, int world) {
+    if (!ctx || !unique_id128) return NBODY_ERR_INVALID;
+    if (world < 1 || rank < 0 || rank >= world) return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_comm_init: rank outside [0, world)");
+    return guarded(ctx, [&]() -> int {
+        int r = set_device(ctx);
+        if (r) return r;
+        return nb_comm_init(ctx, unique_id128, rank, world);
+    });
 }
 
 }  // extern "C"

@@ -33,13 +33,17 @@ struct nbody_ctx {
     // All-pairs scratch: per source-slice partial accelerations [slices][i_count].
     float4* acc_part = nullptr;
     uint64_t acc_part_slices = 0;
-    float4* acc_tmp = nullptr;  // [n] forces-only output / finalize target
+    float4* acc_tmp = nullptr;  // [n] forces-only output / finalize target; NBODY_BUF_ACC_PARTIAL
+    float4* stage = nullptr;    // [n] staging of positions on their way to / from the host (lazily allocated)
+    int pending_forces = 0;     // acc_tmp holds forces awaiting integration: 1 nbody_allpairs_partial, 2 nbody_bh_forces_ranked
     float4* acc_body = nullptr; // [n] accelerations brought back from sorted-rank to body order (lazily allocated)
 
     // Octree state (octree.hip)
     struct Octree* tree = nullptr;
     // symmetric all-pairs plan and scratch (allpairs_sym.hip)
     struct SymPlan* sym = nullptr;
+    // RCCL communicator and the ranks' ranges (comm.hip); null on a single-GPU context
+    struct NbComm* comm = nullptr;
 
     // energy scratch
     double* energy_dev = nullptr;
@@ -92,6 +96,17 @@ void nb_sym_destroy(nbody_ctx* ctx);
 // diag_out: 256 * tpl / NB_DIAG_TILE slices of n entries each, to be summed
 constexpr int NB_DIAG_TILE = 512;
 int nb_allpairs_diag(nbody_ctx* ctx, const float4* posm_in, float4* diag_out, int tpl);
+
+// multi-GPU exchange (comm.hip)
+int nb_comm_unique_id(void* id128);
+int nb_comm_init(nbody_ctx* ctx, const void* id128, int rank, int world);
+void nb_comm_destroy(nbody_ctx* ctx);
+int nb_comm_gather_positions(nbody_ctx* ctx);   // every rank's own targets of posm[cur] to every rank
+int nb_comm_allreduce_partial(nbody_ctx* ctx);  // acc_tmp summed over the ranks
+int nb_comm_gather_ranked(nbody_ctx* ctx);      // acc_tmp by sorted rank: every rank's run to every rank
+void nb_comm_run(const nbody_ctx* ctx, int k, uint64_t* begin, uint64_t* count);
+int nb_comm_rank(const nbody_ctx* ctx);
+int nb_comm_world(const nbody_ctx* ctx);
 
 // octree (octree.hip)
 int nb_tree_create(nbody_ctx* ctx);

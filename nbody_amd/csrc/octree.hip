@@ -964,31 +964,34 @@ MacScale mac_scale(const nbody_ctx* ctx) {
     return MacScale{1.0f / (th2 * (1.0f + 4e-6f)), 1.0f / (th2 * (1.0f - 4e-6f)), soft * (1.0f - 1e-6f), soft * (1.0f + 1e-6f)};
 }
 
+// Grows the node arrays.  They are released first; if one of the new allocations then fails the
+// context is left WITHOUT a tree (have_tree false, capacity 0), so nothing traverses freed arrays.
 int ensure_nodes(nbody_ctx* ctx, Octree* T, uint64_t need) {
     if (need <= T->cap_nodes) return NBODY_OK;
     uint64_t cap = std::max<uint64_t>(need + need / 4 + 1024, 2 * T->n + 1024);
     if (cap > 0xfffffff0ull) return nb_fail(ctx, NBODY_ERR_CAPACITY, "octree needs more than 2^32 nodes");
-    if (T->nodes) NB_HIP(ctx, hipFree(T->nodes));
-    if (T->node_head) NB_HIP(ctx, hipFree(T->node_head));
-    T->node_head = nullptr;
-    if (T->bmin) NB_HIP(ctx, hipFree(T->bmin));
-    if (T->bmax) NB_HIP(ctx, hipFree(T->bmax));
-    if (T->range) NB_HIP(ctx, hipFree(T->range));
-    T->range = nullptr;
-    T->nodes = nullptr;
-    T->bmin = T->bmax = nullptr;
-    T->cap_nodes = 0;
-    // the traversal fetches whole batches: pad so that the last group's batch stays inside
-    NB_HIP(ctx, hipMalloc(&T->nodes, (cap + WALK_BATCH) * sizeof(QNode)));
-    NB_HIP(ctx, hipMalloc(&T->range, cap * sizeof(float)));
-    if (ctx->cfg.quadrupole) {
-        if (T->quad) NB_HIP(ctx, hipFree(T->quad));
-        T->quad = nullptr;
-        NB_HIP(ctx, hipMalloc(&T->quad, (cap + WALK_BATCH) * 8 * sizeof(float)));
+    void** arrays[] = {(void**)&T->nodes, (void**)&T->node_head, (void**)&T->bmin, (void**)&T->bmax, (void**)&T->range, (void**)&T->quad};
+    for (void** a : arrays) {
+        if (*a) (void)hipFree(*a);
+        *a = nullptr;
     }
-    NB_HIP(ctx, hipMalloc(&T->node_head, cap * sizeof(uint32_t)));
-    NB_HIP(ctx, hipMalloc(&T->bmin, cap * sizeof(float4)));
-    NB_HIP(ctx, hipMalloc(&T->bmax, cap * sizeof(float4)));
+    T->cap_nodes = 0;
+    T->have_tree = false;
+    // the traversal fetches whole batches: pad so that the last group's batch stays inside
+    hipError_t e = hipMalloc(&T->nodes, (cap + WALK_BATCH) * sizeof(QNode));
+    if (e == hipSuccess) e = hipMalloc(&T->range, cap * sizeof(float));
+    if (e == hipSuccess && ctx->cfg.quadrupole) e = hipMalloc(&T->quad, (cap + WALK_BATCH) * 8 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&T->node_head, cap * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&T->bmin, cap * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc(&T->bmax, cap * sizeof(float4));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        for (void** a : arrays) {
+            if (*a) (void)hipFree(*a);
+            *a = nullptr;
+        }
+        return nb_fail(ctx, NBODY_ERR_NOMEM, std::string("octree nodes: ") + hipGetErrorString(e));
+    }
     T->cap_nodes = cap;
     return NBODY_OK;
 }

@@ -91,6 +91,16 @@ def accel_allpairs_noalloc(dev_posm, dev_vel16, n_bodies, law, G, eps2, dev_acc1
         raise NBodyError(rc, lib.nbody_last_error(None).decode())
 
 
+def comm_unique_id():
+    """128 bytes identifying a new RCCL communicator (call on one rank, hand them to the others)."""
+    lib = _lib.load()
+    buf = C.create_string_buffer(128)
+    rc = lib.nbody_comm_unique_id(buf)
+    if rc:
+        raise NBodyError(rc, lib.nbody_last_error(None).decode())
+    return buf.raw
+
+
 class NBodySim:
     def __init__(self, n_bodies, **cfg):
         self.lib = _lib.load()
@@ -137,6 +147,13 @@ class NBodySim:
         fn = self.lib.nbody_download_alt if alt else self.lib.nbody_download
         self._ck(fn(self.h, _ptr(p), _ptr(v), _ptr(a)))
         return p, v, a
+
+    def comm_init(self, unique_id, rank, world):
+        """Attach an RCCL communicator (collective over the ranks): step_allpairs / step_bh then exchange
+        inside the library."""
+        if len(unique_id) != 128:
+            raise ValueError("unique_id must be the 128 bytes of comm_unique_id()")
+        self._ck(self.lib.nbody_comm_init(self.h, C.create_string_buffer(unique_id, 128), rank, world))
 
     # -- steps ---------------------------------------------------------------------------------
     def step_allpairs(self, nsteps=1):

@@ -83,7 +83,8 @@ pub struct nbody_counters_t {
     pub bh_wave_node_visits: u64,
     pub octree_nodes: u64,
     pub bh_max_stack: u64,
-    pub reserved: [u64; 7],
+    pub allpairs_path: u64,
+    pub reserved: [u64; 6],
 }
 
 #[repr(C)]
@@ -109,6 +110,9 @@ extern "C" {
     pub fn nbody_integrate_partial(ctx: *mut nbody_ctx) -> c_int;
     pub fn nbody_bh_forces_ranked(ctx: *mut nbody_ctx, rank_begin: u64, rank_count: u64) -> c_int;
     pub fn nbody_integrate_ranked(ctx: *mut nbody_ctx) -> c_int;
+    /// No counterpart in the reference: RCCL communicator inside the library (one process per GPU).
+    pub fn nbody_comm_unique_id(id_out128: *mut c_void) -> c_int;
+    pub fn nbody_comm_init(ctx: *mut nbody_ctx, unique_id128: *const c_void, rank: c_int, world: c_int) -> c_int;
     pub fn nbody_accel_allpairs(ctx: *mut nbody_ctx, host_acc16_out: *mut f32) -> c_int;
     /// No counterpart in the reference: for callers that cannot allocate device memory.
     pub fn nbody_accel_allpairs_noalloc(dev_posm: *const f32, dev_vel16: *const f32, n_bodies: u64, law: c_int, g: f32, eps2: f32, dev_acc16_out: *mut f32, stream: *mut c_void) -> c_int;

@@ -59,7 +59,15 @@ def test_create_rejects_bad_config_without_gpu():
     cfg.shard_begin = 8
     cfg.shard_count = 5
     assert lib.nbody_create(C.byref(h), C.byref(cfg)) == -1
+    cfg.shard_begin = 2
+    cfg.shard_count = 2 ** 64 - 1  # begin + count wraps around to 1
+    assert lib.nbody_create(C.byref(h), C.byref(cfg)) == -1
+    assert b"shard range" in lib.nbody_last_error(None)
     assert lib.nbody_create(None, None) == -1
+    # the allocation-free entry point refuses before it touches a device
+    assert lib.nbody_accel_allpairs_noalloc(None, None, 10, 2, 1.0, 1.0, None, None) == -1
+    assert b"noalloc" in lib.nbody_last_error(None)
+    assert lib.nbody_comm_init(None, None, 0, 1) == -1
 
 
 def test_generators_match_numpy(orc):

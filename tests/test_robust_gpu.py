@@ -1,0 +1,102 @@
+"""Degenerate inputs and call orders: piles of bodies in one depth-cap cell, coincident bodies in
+the clamp corner, and the exchange buffer's ownership between a force call and its integration."""
+import time
+
+import numpy as np
+import pytest
+
+import nbody_amd as nb
+
+pytestmark = pytest.mark.gpu
+
+
+def _pile(n_pile, n_rest, coincident):
+    """n_pile bodies inside ONE depth-16 cell (or all at the clamp corner) plus a uniform rest."""
+    m, p = nb.gen_refcube(n_pile + n_rest, seed=9)
+    cell = 250.0 / 65536
+    if coincident:
+        p[:n_pile, :3] = 250.0  # where src/nbodybh.wgsl:167 piles escapers up
+    else:
+        rng = np.random.default_rng(1)
+        base = np.float32(cell) * np.array([20000, 31000, 40000], np.float32)
+        p[:n_pile, :3] = base + (rng.random((n_pile, 3)) * 0.9 * cell + 0.05 * cell).astype(np.float32)
+    return m, p
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("coincident", [False, True])
+def test_pile_in_one_cell_builds_and_walks_in_bounded_time(orc, mode, coincident):
+    n_pile, n_rest = 100000, 3000
+    n = n_pile + n_rest
+    m, p = _pile(n_pile, n_rest, coincident)
+    # counts of a few targets inside the pile and outside it, against the oracle's traversal of the same tree bytes
+    targets = [(0, 64), (n_pile - 64, 128), (n - 64, 64)]
+    with nb.NBodySim(n, law=nb.LAW_PLUMMER, leaflist_mode=mode) as sim:
+        sim.upload(m, p)
+        sim.build_octree(); sim.sync()
+        t0 = time.time()
+        sim.build_octree(); sim.sync()
+        t_build = time.time() - t0
+        nodes = sim.download_octree()
+        keys, depth, _ = sim.morton_keys()
+        t0 = time.time()
+        acc = sim.accel_bh()
+        t_walk = time.time() - t0
+        sim.set_counting(True)
+        sim.accel_bh()
+        c_all = sim.counters()
+    assert t_build < 1.0 and t_walk < 5.0, (t_build, t_walk)
+    assert np.isfinite(acc[n_pile:]).all()
+    assert c_all["bh_max_stack"] <= 8 * 18
+    # the pile is one LEAFLIST node with the reference's member count (literal: k - 1 prefix aggregates)
+    lists = nodes[nodes["node_type"] == nb.NODE_LEAFLIST]
+    assert lists["child"][:, 1].max() == (n_pile if mode else n_pile - 1)
+    assert len(np.unique(keys[:n_pile])) == 1 and (depth[:n_pile] == 16).all()
+    ref_nodes, _, _, _ = orc.build_octree(p, m, leaflist_mode=mode)
+    assert len(ref_nodes) == len(nodes)
+    onodes = nodes.view(orc.NODE_DTYPE)
+    for b, cnt in targets:
+        ref, rc = orc.bh_accel(orc.LAW_PLUMMER, p, np.zeros_like(p), onodes, i_begin=b, i_count=cnt)
+        with nb.NBodySim(n, law=nb.LAW_PLUMMER, leaflist_mode=mode, shard_begin=b, shard_count=cnt) as sim:
+            sim.upload(m, p)
+            sim.build_octree()
+            sim.set_counting(True)
+            got = sim.accel_bh()
+            c = sim.counters()
+        assert (c["bh_node_visits"], c["bh_leaf_interactions"], c["bh_aggregate_interactions"]) == \
+            (rc["visits"], rc["leaf"], rc["aggregate"]), (b, cnt)
+        r, g = ref[b:b + cnt, :3], got[b:b + cnt, :3]
+        ok = np.isfinite(r).all(axis=1)  # coincident bodies with eps2 > 0 stay finite; keep the mask anyway
+        scale = np.linalg.norm(r[ok], axis=1)
+        assert (np.linalg.norm(g[ok] - r[ok], axis=1) <= 2e-4 * scale + 1e-7).all()
+
+
+def test_exchange_buffer_is_not_touched_by_transfers_and_stale_forces_are_refused():
+    n = 70000
+    m, p, v = nb.gen_plummer(n, seed=4)
+    with nb.NBodySim(n, law=nb.LAW_PLUMMER) as sim:
+        sim.upload(m, p, v)
+        with pytest.raises(nb.NBodyError) as e:
+            sim.integrate_partial()  # nothing to integrate yet
+        assert e.value.code == -4
+        sim.allpairs_partial(0, 1)
+        before = sim.read_buffer(nb.BUF_ACC_PARTIAL)
+        sim.download()            # positions pass through a buffer of their own
+        sim.upload_alt(p, v)
+        assert np.array_equal(before, sim.read_buffer(nb.BUF_ACC_PARTIAL))
+        sim.integrate_partial()
+        with pytest.raises(nb.NBodyError):
+            sim.integrate_partial()  # consumed
+        sim.allpairs_partial(0, 1)
+        sim.accel_allpairs()      # overwrites the exchange buffer
+        with pytest.raises(nb.NBodyError) as e:
+            sim.integrate_partial()
+        assert e.value.code == -4
+    with nb.NBodySim(5000, law=nb.LAW_PLUMMER) as sim:
+        m, p = nb.gen_refcube(5000)
+        sim.upload(m, p)
+        with pytest.raises(nb.NBodyError) as e:
+            sim.integrate_ranked()
+        assert e.value.code == -4
+        sim.bh_forces_ranked(0, 5000)
+        sim.integrate_ranked()

@@ -21,6 +21,11 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_INTERACTION = {"plummer": 20, "wgsl_bias": 46, "cpu_r6": 20}
 PEAK_FP32_TFLOPS = 157.3  # MI355X FP32 vector peak (256 CU x 256 flop/clk x 2.4 GHz)
+FLOP_PER_CLOCK = 256 * 256  # whole chip, FP32 vector
+# what the pair kernel executes per UNORDERED pair (equal masses): 3 sub, 3 fma for r^2, rsq,
+# 2 mul for r^-3, 3 fma on the targets, 3 mul/fma for the reaction = 24 flop (26 with unequal masses)
+EXECUTED_FLOP_PER_PAIR = 24
+PEAK_HBM_GBPS = 8000.0
 
 
 def cpu_baseline(seconds_budget=10.0):
@@ -76,9 +81,9 @@ def main():
     ap.add_argument("--bh-balance-every", type=int, default=0,
                     help="Barnes-Hut legs on several GPUs: every K steps move the ranks' runs of the sorted order after "
                          "their measured traversal times (0: equal runs; a centred Plummer sphere is balanced as it is)")
-    ap.add_argument("--config2", action="store_true",
-                    help="add all-pairs legs at N=65536 (they launch the headline kernel too, which would blur its "
-                         "average in a profile of this command, so they are off by default)")
+    ap.add_argument("--no-config2", action="store_true",
+                    help="skip the all-pairs legs at N=65536 (the reference's own GPU scale); in a kernel trace of this "
+                         "command they are told from the headline launches by their grid size")
     args = ap.parse_args()
 
     import torch
@@ -130,6 +135,8 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         kms, launches = be.sim.kernel_time()
+        clock = be.sim.kernel_clock()
+        path = be.sim.counters()["allpairs_path"]
         agree = True
         if world > 1:
             t = torch.tensor([dt, kms], device="cuda", dtype=torch.float64)
@@ -144,14 +151,14 @@ def main():
             dist.all_reduce(hi, op=dist.ReduceOp.MAX)
             agree = bool(lo.item() == hi.item()) and bool(torch.isfinite(cs).item())
         be.sim.close()
-        return dt, kms, launches, agree
+        return dt, kms, launches, agree, clock, path
 
     pair = world > 1 and args.law == "plummer" and n >= HipShardBackend.PAIR_SHARD_MIN_N
     scheme = "single" if world == 1 else (f"pair-shard x{world}" if pair else f"target-shard x{world}")
     scheme_text = ("" if world == 1 else
                    ": pair tiles dealt over the ranks, per-step all-reduce of partial accelerations + all-gather of positions"
                    if pair else ": targets split by index range, per-step all-gather of positions")
-    dt, kernel_ms, launches, agree = timed_run(law, args.steps, args.warmup)
+    dt, kernel_ms, launches, agree, clock_mhz, path = timed_run(law, args.steps, args.warmup)
     interactions = float(n) * n * args.steps
     flop = FLOP_PER_INTERACTION[args.law]
     # the dominant kernel: one launch covers this rank's share of the N x N interactions (its
@@ -177,27 +184,38 @@ def main():
                    "n_bodies": n, "law": args.law, "parallelism": scheme},
         "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
-                     "kernel": ("k_ap_sym" if (args.law == "plummer" and n >= 65536) else
-                                "k_allpairs_plummer_pk" if args.law == "plummer" else "k_allpairs"),
+                     "kernel": ("k_ap_sym" if path == 2 else "k_allpairs_plummer_pk" if args.law == "plummer" else "k_allpairs"),
                      "kernel_ms": kernel_ms, "launches": launches, "flop_per_interaction": flop,
-                     "note": "FP32 vector (VALU) roofline, algorithmic 20 flop per ordered interaction x N^2. k_ap_sym "
-                             "evaluates each unordered pair once (Newton's third law), so it executes about half of "
-                             "those flops; the plain kernel (one evaluation per ordered pair) reaches 0.57 of peak"},
+                     "note": "FP32 vector (VALU) roofline. `achieved`/`frac` price the ALGORITHMIC work, 20 flop per "
+                             "ordered interaction x N^2; k_ap_sym evaluates each unordered pair once (Newton's third "
+                             "law), so what it EXECUTES is `executed_tflops`/`executed_frac` (24 flop per unordered "
+                             "pair); `*_at_clock` price against the peak at the shader clock measured in the kernel"},
     }
+    rf = out["roofline"]
+    if path == 2:
+        executed = per_launch / 2 * EXECUTED_FLOP_PER_PAIR / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+        rf.update({"executed_flop_per_unordered_pair": EXECUTED_FLOP_PER_PAIR, "executed_tflops": executed,
+                   "executed_frac": executed / PEAK_FP32_TFLOPS})
+    else:
+        rf.update({"executed_tflops": achieved, "executed_frac": achieved / PEAK_FP32_TFLOPS})
+    if clock_mhz > 0:
+        peak_clk = FLOP_PER_CLOCK * clock_mhz * 1e6 / 1e12
+        rf.update({"shader_clock_mhz": clock_mhz, "peak_at_clock": peak_clk, "frac_at_clock": achieved / peak_clk,
+                   "executed_frac_at_clock": rf["executed_tflops"] / peak_clk})
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process;
     # the value measured with rocprofv3 (separate FETCH_SIZE / WRITE_SIZE passes over this same
     # command) is kept under profiles/ and quoted when it is for this workload.
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_allpairs.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_allpairs.json")))
         if (pmc["n_bodies"], pmc["n_gpus"], pmc["law"]) == (n, args.gpus, args.law) and out["roofline"]["kernel"] in pmc["kernels"]:
             out["roofline"]["traffic"] = pmc["kernels"][out["roofline"]["kernel"]]["hbm_bytes_per_launch"]
-            out["roofline"]["traffic_source"] = "profiles/r01_pmc_allpairs.json (rocprofv3 --pmc, offline)"
+            out["roofline"]["traffic_source"] = "profiles/r02_pmc_allpairs.json (rocprofv3 --pmc over this command, offline)"
     except (OSError, KeyError, ValueError):
         pass
     if not args.no_extras and args.law == "plummer":
         # the reference's shader law (src/nbody.wgsl:54-81) on the same bodies, fewer steps
         wsteps = max(1, min(2, args.steps))
-        wdt, wk, _, wagree = timed_run(nb.LAW_WGSL_BIAS, wsteps, 1)
+        wdt, wk, _, wagree, _, _ = timed_run(nb.LAW_WGSL_BIAS, wsteps, 1)
         agree = agree and wagree
         wach = per_launch * FLOP_PER_INTERACTION["wgsl_bias"] / (wk * 1e-3) / 1e12 if wk > 0 else 0.0
         out["wgsl_bias_law"] = {"value": float(n) * n * wsteps / wdt, "unit": "interactions/s",
@@ -210,12 +228,19 @@ def main():
         with nb.NBodySim(nsmall, law=law_id) as s_:
             s_.upload(m_, p_, v_)
             s_.step_allpairs(3)
+            s_.set_kernel_timing(True)
             s_.sync()
             t0 = time.perf_counter()
             s_.step_allpairs(steps)
             s_.sync()
             sdt = time.perf_counter() - t0
-        return {"interactions_per_s": float(nsmall) * nsmall * steps / sdt, "ms_per_step": sdt / steps * 1e3, "steps": steps}
+            skm, _ = s_.kernel_time()
+            spath = s_.counters()["allpairs_path"]
+        fl = FLOP_PER_INTERACTION["plummer" if law_id == nb.LAW_PLUMMER else "wgsl_bias"]
+        ach = float(nsmall) * nsmall * fl / (skm * 1e-3) / 1e12 if skm > 0 else 0.0
+        return {"interactions_per_s": float(nsmall) * nsmall * steps / sdt, "ms_per_step": sdt / steps * 1e3, "steps": steps,
+                "kernel": "k_ap_sym" if spath == 2 else "plain", "kernel_ms": skm, "achieved_tflops": ach,
+                "frac": ach / PEAK_FP32_TFLOPS, "flop_per_interaction": fl}
 
     def bh_leg(nbodies, bsteps, bh_law=None):
         """Barnes-Hut step, theta = 0.5, depth cap 16.  With several GPUs every rank holds all bodies:
@@ -270,12 +295,20 @@ def main():
                 "steps_per_s": bsteps / bdt, "ms_per_step": bdt / bsteps * 1e3, "walk_kernel_ms": wms,
                 "build_ms": bms,
                 "build_roofline": {"bound": "hbm", "achieved": build_bytes / (bms * 1e-3) / 1e9 if bms > 0 else None,
-                                   "peak": 8000.0, "unit": "GB/s",
-                                   "frac": build_bytes / (bms * 1e-3) / 1e9 / 8000.0 if bms > 0 else None},
+                                   "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                                   "frac": build_bytes / (bms * 1e-3) / 1e9 / PEAK_HBM_GBPS if bms > 0 else None,
+                                   "bytes_per_build": build_bytes},
                 "octree_nodes": c["octree_nodes"], "interactions_per_step": inter,
                 "interactions_per_s": inter * bsteps / bdt, "node_visits_per_body": visits / nbodies,
                 "wave_node_visits": wave_visits,
-                "walk_requested_GBps_per_gpu": walk_bytes / (wms * 1e-3) / 1e9 if wms > 0 else None,
+                "walk_roofline": {"bound": "hbm", "achieved": walk_bytes / (wms * 1e-3) / 1e9 if wms > 0 else None,
+                                  "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                                  "frac": walk_bytes / (wms * 1e-3) / 1e9 / PEAK_HBM_GBPS if wms > 0 else None,
+                                  "traffic": None, "kernel": "k_walk", "kernel_ms": wms,
+                                  "bytes_per_launch": walk_bytes,
+                                  "note": "algorithmic bytes = 32 B x wavefront node visits + 48 B per body, per GPU; the "
+                                          "records are served by L2 / Infinity Cache and the kernel is bound by instruction "
+                                          "issue (17 VALU + 12 scalar instructions per wavefront visit), not by HBM"},
                 "equivalent_allpairs_interactions_per_s": float(nbodies) * nbodies * bsteps / bdt}
 
     def extra(key, fn):
@@ -289,7 +322,7 @@ def main():
         except Exception as e:
             out[key] = {"error": f"{type(e).__name__}: {e}"}
 
-    if args.config2 and world == 1:
+    if not args.no_config2 and not args.no_extras and world == 1:
         extra("allpairs_n65536", lambda: {"plummer": small_leg(65536, nb.LAW_PLUMMER, 50),
                                           "wgsl_bias": small_leg(65536, nb.LAW_WGSL_BIAS, 10)})
     if not args.no_extras and args.law == "plummer":
@@ -298,6 +331,7 @@ def main():
         extra("barnes_hut_wgsl_bias_law", lambda: bh_leg(n, 10, nb.LAW_WGSL_BIAS))
         if n == 1 << 20:
             extra("barnes_hut_16m", lambda: bh_leg(1 << 24, 5))
+            extra("barnes_hut_16m_wgsl_bias_law", lambda: bh_leg(1 << 24, 3, nb.LAW_WGSL_BIAS))
     if rank == 0 and args.gpus == 1 and not args.no_extras:
         try:
             out["cpu_baseline"] = cpu_baseline()

@@ -265,6 +265,12 @@ void* nbody_stream(nbody_ctx* ctx);
  * kernels).  Measured with HIP events on the context's stream; *launches receives the count.  Blocks. */
 int nbody_kernel_time(nbody_ctx* ctx, int which, double* avg_ms, uint64_t* launches);
 int nbody_set_kernel_timing(nbody_ctx* ctx, int on);
+/* The shader clock (MHz) one workgroup of the LAST pair-kernel launch (all-pairs, PLUMMER law,
+ * N >= 65,536) ran at: its shader-cycle count over its 100 MHz real-time count, stamped around a
+ * work item in the middle of the dispatch while kernel timing was on.  0 when there was no such
+ * launch.  For pricing the FP32 peak at the clock the chip actually held.  Blocks.  No
+ * counterpart in the reference. */
+int nbody_kernel_clock(nbody_ctx* ctx, double* mhz);
 
 /* Synthetic initial conditions (host code, no GPU).  Counter-based splitmix64 stream: draw k of
  * body i is mix64(seed + (64*i + k + 1) * 0x9E3779B97F4A7C15), u = (x >> 40) * 2^-24.

@@ -85,6 +85,7 @@ SYMBOLS = {
     "nbody_stream": (_P, [_P]),
     "nbody_kernel_time": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "nbody_set_kernel_timing": (C.c_int, [_P, C.c_int]),
+    "nbody_kernel_clock": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "nbody_gen_refcube": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_float, _P, _P]),
     "nbody_gen_plummer": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_float, C.c_float, C.c_float,
                                     C.c_float, C.c_float, C.c_int, _P, _P, _P]),

@@ -524,35 +524,53 @@ void ap_finalize(const ApLaunch& a, int law, const ApPlan& pl, float G, float4* 
 
 }  // namespace
 
+// Kernel timing with HIP events on the context's stream.  The events come from a pool that
+// nbody_set_kernel_timing(on) fills, so a timed launch creates nothing; the pool only grows (by
+// one pair) when more launches than it holds are enqueued between two collections.
+int nb_time_reserve(nbody_ctx* ctx, size_t pairs) {
+    for (auto& v : ctx->ev) {
+        while (v.size() < 2 * pairs) {
+            hipEvent_t e = nullptr;
+            NB_HIP(ctx, hipEventCreate(&e));
+            v.push_back(e);
+        }
+    }
+    return NBODY_OK;
+}
 void nb_time_begin(nbody_ctx* ctx, int which) {
     if (!ctx->timing) return;
     auto& v = ctx->ev[which];
-    if (v.size() >= 2048) nb_time_collect(ctx, which);
-    hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return;
-    v.push_back(e0);
-    v.push_back(e1);
-    hipEventRecord(e0, ctx->stream);
+    size_t& used = ctx->ev_used[which];
+    if (used + 2 > v.size()) {
+        if (v.size() >= 4096) nb_time_collect(ctx, which);
+        else {
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return;
+            v.push_back(e0);
+            v.push_back(e1);
+        }
+    }
+    hipEventRecord(v[used], ctx->stream);
+    used += 2;
 }
 void nb_time_end(nbody_ctx* ctx, int which) {
     if (!ctx->timing) return;
-    auto& v = ctx->ev[which];
-    if (v.size() >= 2) hipEventRecord(v.back(), ctx->stream);
+    const size_t used = ctx->ev_used[which];
+    if (used >= 2) hipEventRecord(ctx->ev[which][used - 1], ctx->stream);
 }
 int nb_time_collect(nbody_ctx* ctx, int which) {
     auto& v = ctx->ev[which];
-    if (v.empty()) return NBODY_OK;
+    size_t& used = ctx->ev_used[which];
+    if (used == 0) return NBODY_OK;
     NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (size_t k = 0; k + 1 < v.size(); k += 2) {
+    for (size_t k = 0; k + 1 < used; k += 2) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, v[k], v[k + 1]) == hipSuccess) {
             ctx->time_acc_ms[which] += ms;
             ctx->time_launches[which] += 1;
         }
-        hipEventDestroy(v[k]);
-        hipEventDestroy(v[k + 1]);
     }
-    v.clear();
+    used = 0;
     return NBODY_OK;
 }
 

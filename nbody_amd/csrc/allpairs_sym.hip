@@ -49,7 +49,16 @@ template <bool UNIFORM, int P>
 __global__ __launch_bounds__(256) void k_ap_sym(const float4* __restrict__ posm, int n, const SymItem* __restrict__ items,
                                                 const unsigned long long* __restrict__ rowoff,
                                                 float4* __restrict__ part_j, float4* __restrict__ part_i, float eps2,
-                                                uint32_t part, uint32_t nparts, uint32_t n_items) {
+                                                uint32_t part, uint32_t nparts, uint32_t n_items,
+                                                unsigned long long* __restrict__ clk) {
+    // One workgroup in the middle of the dispatch stamps the shader-cycle counter and the
+    // 100 MHz real-time counter around its work item: their ratio is the clock the chip held.
+    const bool stamp = clk != nullptr && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0;
+    unsigned long long c0 = 0, r0 = 0;
+    if (stamp) {
+        c0 = __builtin_amdgcn_s_memtime();
+        r0 = __builtin_amdgcn_s_memrealtime();
+    }
     // sources are stored twice (entries k and k+64) so that lane + t never needs a modulo
     __shared__ float4 tile[2][2 * TILE];
     __shared__ float4 accj[3][4][2 * TILE];
@@ -169,6 +178,10 @@ __global__ __launch_bounds__(256) void k_ap_sym(const float4* __restrict__ posm,
     for (int h = 0; h < H; ++h) {
         pi[(2 * h) * 64] = make_float4(ax[h].x, ay[h].x, az[h].x, 0.0f);
         pi[(2 * h + 1) * 64] = make_float4(ax[h].y, ay[h].y, az[h].y, 0.0f);
+    }
+    if (stamp) {
+        clk[0] = __builtin_amdgcn_s_memtime() - c0;
+        clk[1] = __builtin_amdgcn_s_memrealtime() - r0;
     }
 }
 
@@ -384,7 +397,7 @@ int nb_allpairs_forces_sym(nbody_ctx* ctx, const float4* posm_in, float4* acc_ou
     if (P->n_items) {
 #define NB_SYM_LAUNCH(U, T)                                                                                          \
     hipLaunchKernelGGL((k_ap_sym<U, T>), dim3((P->n_items + nparts - 1) / nparts), dim3(256), 0, ctx->stream, posm_in, n, \
-                       P->items, P->rowoff, P->part_j, P->part_i, ctx->cfg.eps2, part, nparts, P->n_items)
+                       P->items, P->rowoff, P->part_j, P->part_i, ctx->cfg.eps2, part, nparts, P->n_items, ctx->clk_dev)
         if (uniform && tpl == 16) NB_SYM_LAUNCH(true, 16);
         else if (tpl == 16) NB_SYM_LAUNCH(false, 16);
         else if (uniform && tpl == 8) NB_SYM_LAUNCH(true, 8);

@@ -237,6 +237,7 @@ void nbody_destroy(nbody_ctx* ctx) {
     if (ctx->acc_body) hipFree(ctx->acc_body);
     if (ctx->masses) hipFree(ctx->masses);
     if (ctx->energy_dev) hipFree(ctx->energy_dev);
+    if (ctx->clk_dev) hipFree(ctx->clk_dev);
     for (auto& v : ctx->ev)
         for (hipEvent_t e : v) hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
@@ -627,8 +628,37 @@ void* nbody_stream(nbody_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; 
 
 int nbody_set_kernel_timing(nbody_ctx* ctx, int on) {
     if (!ctx) return NBODY_ERR_INVALID;
-    ctx->timing = on != 0;
-    return NBODY_OK;
+    return guarded(ctx, [&]() -> int {
+        int r = set_device(ctx);
+        if (r) return r;
+        if (on) {
+            // everything a timed launch needs exists before the first one: a pool of event pairs and
+            // the clock stamp words of the pair kernel
+            r = nb_time_reserve(ctx, 64);
+            if (r) return r;
+            if (!ctx->clk_dev) {
+                NB_HIP(ctx, hipMalloc(&ctx->clk_dev, 2 * sizeof(unsigned long long)));
+                NB_HIP(ctx, hipMemsetAsync(ctx->clk_dev, 0, 2 * sizeof(unsigned long long), ctx->stream));
+            }
+        }
+        ctx->timing = on != 0;
+        return NBODY_OK;
+    });
+}
+
+int nbody_kernel_clock(nbody_ctx* ctx, double* mhz) {
+    if (!ctx || !mhz) return NBODY_ERR_INVALID;
+    return guarded(ctx, [&]() -> int {
+        int r = set_device(ctx);
+        if (r) return r;
+        *mhz = 0.0;
+        if (!ctx->clk_dev) return NBODY_OK;
+        unsigned long long h[2] = {0, 0};
+        NB_HIP(ctx, hipMemcpyAsync(h, ctx->clk_dev, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+        NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (h[1] > 0) *mhz = 100.0 * (double)h[0] / (double)h[1];
+        return NBODY_OK;
+    });
 }
 
 int nbody_kernel_time(nbody_ctx* ctx, int which, double* avg_ms, uint64_t* launches) {

@@ -54,7 +54,9 @@ struct nbody_ctx {
     bool leapfrog_started = false;  // NBODY_INT_LEAPFROG: a step has been taken since the last upload
     // kernel timing (HIP events on `stream`)
     bool timing = false;
-    std::vector<hipEvent_t> ev[3];  // 0 all-pairs force kernel, 1 traversal kernel, 2 octree build (all its launches)
+    std::vector<hipEvent_t> ev[3];  // 0 all-pairs force kernel, 1 traversal kernel, 2 octree build (all its launches):
+    size_t ev_used[3] = {0, 0, 0};  // a pool of event pairs, created when timing is switched on and reused
+    unsigned long long* clk_dev = nullptr;  // {shader cycles, 100 MHz ticks} of one workgroup of the last pair-kernel launch
     double time_acc_ms[3] = {0, 0, 0};
     uint64_t time_launches[3] = {0, 0, 0};
 };
@@ -83,6 +85,7 @@ int nb_energy(nbody_ctx* ctx, double* kinetic, double* potential);
 void nb_time_begin(nbody_ctx* ctx, int which);
 void nb_time_end(nbody_ctx* ctx, int which);
 int nb_time_collect(nbody_ctx* ctx, int which);
+int nb_time_reserve(nbody_ctx* ctx, size_t pairs);  // event pairs ready for each kind of launch
 
 const char* nb_noalloc_last_error();
 void nb_noalloc_clear_error();

@@ -241,6 +241,12 @@ class NBodySim:
         self._ck(self.lib.nbody_kernel_time(self.h, 2 if build else int(bool(bh)), C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
 
+    def kernel_clock(self):
+        """Shader clock (MHz) held during the last pair-kernel launch made with kernel timing on (0: none)."""
+        mhz = C.c_double()
+        self._ck(self.lib.nbody_kernel_clock(self.h, C.byref(mhz)))
+        return mhz.value
+
     def device_buffer(self, which):
         p, b = C.c_void_p(), C.c_size_t()
         self._ck(self.lib.nbody_device_buffer(self.h, which, C.byref(p), C.byref(b)))

@@ -133,6 +133,7 @@ extern "C" {
     pub fn nbody_stream(ctx: *mut nbody_ctx) -> *mut c_void;
     pub fn nbody_kernel_time(ctx: *mut nbody_ctx, which: c_int, avg_ms: *mut f64, launches: *mut u64) -> c_int;
     pub fn nbody_set_kernel_timing(ctx: *mut nbody_ctx, on: c_int) -> c_int;
+    pub fn nbody_kernel_clock(ctx: *mut nbody_ctx, mhz: *mut f64) -> c_int;
     pub fn nbody_gen_refcube(seed: u64, first: u64, count: u64, world: f32, host_masses: *mut f32, host_pos16: *mut f32) -> c_int;
     pub fn nbody_gen_plummer(seed: u64, first: u64, count: u64, n_total: u64, world: f32, a: f32, rmax: f32, total_mass: f32, g: f32, equilibrium: c_int, host_masses: *mut f32, host_pos16: *mut f32, host_vel16: *mut f32) -> c_int;
 }

@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--bh-balance-every", type=int, default=0,
                     help="Barnes-Hut legs on several GPUs: every K steps move the ranks' runs of the sorted order after "
                          "their measured traversal times (0: equal runs; a centred Plummer sphere is balanced as it is)")
+    ap.add_argument("--comm", default="torch", choices=["torch", "library"],
+                    help="who runs the per-step exchange on several GPUs: torch.distributed collectives issued from "
+                         "Python (default), or the library's own RCCL communicator (nbody_comm_init)")
     ap.add_argument("--no-config2", action="store_true",
                     help="skip the all-pairs legs at N=65536 (the reference's own GPU scale); in a kernel trace of this "
                          "command they are told from the headline launches by their grid size")
@@ -125,7 +128,7 @@ def main():
     def timed_run(law_id, steps, warmup):
         be = HipShardBackend(n, begin, count, local_rank, law=law_id)
         be.upload(masses, pos, vel)
-        sim = ShardedSim(be, n, rank, world)
+        sim = ShardedSim(be, n, rank, world, library_comm=args.comm == "library")
         sim.step_allpairs(warmup)
         be.sim.set_kernel_timing(True)
         be.sim.kernel_time()
@@ -250,7 +253,8 @@ def main():
         b_, c_ = shard_range(nbodies, rank, world)
         be = HipShardBackend(nbodies, b_, c_, local_rank, law=nb.LAW_PLUMMER if bh_law is None else bh_law, bh_ranked=True)
         be.upload(m_, p_, v_)
-        sim = ShardedSim(be, nbodies, rank, world, bh_balance_every=args.bh_balance_every)
+        sim = ShardedSim(be, nbodies, rank, world, bh_balance_every=args.bh_balance_every,
+                         library_comm=args.comm == "library")
         sim.step_bh(2)
         be.sim.set_counting(True)
         be.sim.bh_forces_ranked(*sim.bh_ranges[rank])   # counting build of the traversal kernel, own targets only

@@ -144,8 +144,10 @@ class HipShardBackend:
 
 
 class ShardedSim:
-    def __init__(self, backend, n, rank=None, world=None, group=None, bh_balance_every=0):
-        """bh_balance_every = K > 0 (replicated-state Barnes-Hut only): every K steps the ranks
+    def __init__(self, backend, n, rank=None, world=None, group=None, bh_balance_every=0, library_comm=False):
+        """library_comm: the exchange runs inside the library (nbody_comm_init: RCCL on the context's
+        stream); this class then only hands the communicator's id round and forwards the steps.
+        bh_balance_every = K > 0 (replicated-state Barnes-Hut only): every K steps the ranks
         exchange their measured traversal times and move the boundaries of their runs of the
         sorted order so that the times even out (for bodies that are not spread symmetrically
         over the Morton order; a centred Plummer sphere is balanced within 2 % as it is)."""
@@ -161,6 +163,15 @@ class ShardedSim:
         self.bh_balance_every = bh_balance_every
         self._bh_steps = 0
         self._stage = None
+        self.library_comm = library_comm
+        if library_comm:
+            if bh_balance_every:
+                raise ValueError("the in-library exchange splits the sorted order evenly: no bh_balance_every")
+            # one rank makes the id, the host side (this process group) carries it to the others
+            ids = [backend.sim.comm_unique_id() if self.rank == 0 else None]
+            if self.world > 1:
+                dist.broadcast_object_list(ids, src=0, group=group)
+            backend.sim.comm_init(ids[0], self.rank, self.world)
 
     def _stream(self):
         """Collectives and tensor ops must be enqueued on the stream the backend computes on."""
@@ -220,6 +231,9 @@ class ShardedSim:
     def step_allpairs(self, nsteps=1):
         if self.world > 1 and getattr(self.backend, "bh_ranked", False):
             raise ValueError("a bh_ranked backend holds all bodies on every rank: it is for step_bh only")
+        if self.library_comm:
+            self.backend.sim.step_allpairs(nsteps)
+            return
         pair = self.world > 1 and getattr(self.backend, "pair_sharding", False)
         for _ in range(nsteps):
             if pair:
@@ -234,6 +248,11 @@ class ShardedSim:
 
     def step_bh(self, nsteps=1):
         ranked = getattr(self.backend, "bh_ranked", False)
+        if self.library_comm:
+            if not ranked:
+                raise ValueError("the in-library Barnes-Hut exchange needs a bh_ranked backend (every rank holds all bodies)")
+            self.backend.sim.step_bh(nsteps)
+            return
         for _ in range(nsteps):
             if ranked and self.world > 1:
                 if self.bh_balance_every and self._bh_steps % self.bh_balance_every == 0:

@@ -148,6 +148,10 @@ class NBodySim:
         self._ck(fn(self.h, _ptr(p), _ptr(v), _ptr(a)))
         return p, v, a
 
+    @staticmethod
+    def comm_unique_id():
+        return comm_unique_id()
+
     def comm_init(self, unique_id, rank, world):
         """Attach an RCCL communicator (collective over the ranks): step_allpairs / step_bh then exchange
         inside the library."""

@@ -66,3 +66,15 @@ def test_headless_host_dumps_renderer_frames(tmp_path):
         p, _, _ = sim.download()
     last = np.frombuffer(raw[-16 * n:], np.float32).reshape(n, 4)
     assert np.array_equal(last, p)
+
+
+@pytest.mark.parametrize("mode", ["gpu", "bh"])
+def test_headless_host_with_the_library_communicator(mode):
+    """--comm attaches the in-library RCCL communicator (one rank here: a box has one GPU, and RCCL
+    refuses two ranks on one device); the frames must be those of the plain run."""
+    args = [EXE, "--mode", mode, "--n", "3000", "--frames", "6", "--report", "6", "--seed", "11"]
+    plain = subprocess.run(args, capture_output=True, text=True, timeout=120)
+    comm = subprocess.run(args + ["--ranks", "1", "--comm"], capture_output=True, text=True, timeout=120)
+    assert plain.returncode == 0 and comm.returncode == 0, plain.stderr + comm.stderr
+    frame = lambda out: re.search(r"frame 6: body0 = .*", out).group(0)
+    assert frame(plain.stdout) == frame(comm.stdout)

@@ -44,6 +44,20 @@ torch.cuda.synchronize()
 p, v, a = be.download()
 assert np.array_equal(p, rp) and np.array_equal(v, rv) and np.array_equal(a, ra)
 assert np.array_equal(be.posm().cpu().numpy()[:, :3], p[:, :3])
+# the same two steps with the exchange inside the library (torch only carries the communicator's id);
+# torch's own RCCL is already in the process and is the copy the library binds
+be2 = HipShardBackend(n, 0, n, 0, law=nb.LAW_PLUMMER)
+be2.upload(m, pos, vel)
+sim2 = ShardedSim(be2, n, 0, 1, library_comm=True)
+sim2.step_allpairs(2)
+p2, v2, a2 = be2.download()
+assert np.array_equal(p2, rp) and np.array_equal(v2, rv) and np.array_equal(a2, ra)
+be3 = HipShardBackend(n, 0, n, 0, law=nb.LAW_PLUMMER, bh_ranked=True)
+be3.upload(m, pos, vel)
+ShardedSim(be3, n, 0, 1, library_comm=True).step_bh(2)
+ref = nb.NBodySim(n, law=nb.LAW_PLUMMER); ref.upload(m, pos, vel); ref.step_bh(2); bp, bv, ba = ref.download(); ref.close()
+p3, v3, a3 = be3.download()
+assert np.array_equal(p3, bp) and np.array_equal(v3, bv) and np.array_equal(a3, ba)
 dist.destroy_process_group()
 print("INTEROP_OK")
 '''

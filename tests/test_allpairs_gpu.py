@@ -57,7 +57,11 @@ def test_accel_matches_oracle(orc, law, n):
     # reference order itself drifts past 1e-5 for the worst bodies once N reaches thousands)
     ref32 = orc.accel_allpairs(LAWS[law], pos, vel, m)
     err = body_rel_err(acc, ref32)
-    assert np.quantile(err, 0.99 if n <= 1000 else 0.5) < TOL
+    if law == "cpu_r6":
+        # unsoftened r^-5: a close pair dominates a body's sum and its f32 rounding alone exceeds 1e-5
+        assert np.quantile(err, 0.99 if n <= 1000 else 0.5) < TOL
+    else:
+        assert err.max() < TOL, float(err.max())   # EVERY body within the stated tolerance of the f32 reference
 
 
 @pytest.mark.parametrize("law", ["wgsl_bias", "plummer"])

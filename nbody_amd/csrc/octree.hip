@@ -789,9 +789,13 @@ __device__ __forceinline__ void pin_moment(const QMoment& m) {
     asm volatile("" ::"s"(m.xx), "s"(m.xy), "s"(m.xz), "s"(m.yy), "s"(m.yz), "s"(m.zz));
 }
 
-// Seven wavefronts per SIMD (at most 96 scalar registers; the few that do not fit live in lanes of
-// a vector register): measured 4 % faster at N = 16M than the six the unconstrained allocation
-// (106) is admitted with; eight (80) spills 73 of them and is twice as slow.
+// A popped group's lane set is held in EXEC while its records are visited: inside
+// `if (lane in mask)` the compare of a record is made by the group's lanes only, so "some lane does
+// not clearly accept" is the compare's own result (no mask arithmetic), and where every lane
+// accepts, the term is accumulated without a select.  Groups longer than a batch leave their
+// remainder on the stack.
+// Seven wavefronts per SIMD (at most 96 scalar registers): measured 4 % faster at N = 16M than the
+// six the unconstrained allocation is admitted with; eight (80) spills and is twice as slow.
 template <int LAW, bool COUNT, bool QUAD>
 __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_walk(const QNode* __restrict__ q, const uint32_t* __restrict__ order, uint32_t m,
                                               uint32_t i_begin, const float4* __restrict__ posm,
@@ -800,16 +804,12 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(7,
                                               unsigned long long* __restrict__ counters,
                                               uint32_t* __restrict__ err_flag, int out_by_rank,
                                               const float* __restrict__ quad) {
-    // Target r of this launch is body order[r] (or i_begin + r without an order); its result goes
-    // to acc_out[body], or with out_by_rank to acc_out[i_begin + r].
-    __shared__ uint4 st[WALK_THREADS / 64][WALK_STACK];  // {first, count, mask.lo, mask.hi}
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2): give each XCD one
-    // contiguous eighth of the Morton order, so that it keeps meeting the same part of the tree.
+    __shared__ uint4 stack[WALK_STACK];  // {first, count, mask.lo, mask.hi}
+    const int lane = threadIdx.x;
     const uint32_t nblk = gridDim.x, q8 = nblk / 8, r8 = nblk % 8;
     const uint32_t xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
     const uint32_t blk = xcd * q8 + min(xcd, r8) + slot;
-    const uint32_t r = blk * WALK_THREADS + tid;
+    const uint32_t r = blk * WALK_THREADS + lane;
     const bool valid = r < m;
     const uint32_t b = valid ? (order ? order[r] : i_begin + r) : 0u;
     Tgt t;
@@ -826,93 +826,64 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(7,
     }
     float ax = 0.0f, ay = 0.0f, az = 0.0f;
     uint32_t n_visit = 0, n_leaf = 0, n_agg = 0, n_wave = 0, max_top = 0;
-    uint4* stack = st[wave];
     int top = 0;
     const unsigned long long all = __ballot(valid);
     if (all) {
         stack[0] = make_uint4(0u, 1u, (uint32_t)all, (uint32_t)(all >> 32));  // the root as a one-node group
         top = 1;
     }
+    constexpr int BATCH = QUAD ? WALK_BATCH / 2 : WALK_BATCH;  // with quadrupoles the moments ride along
+    // Where the term is cheap (PLUMMER) it is written twice, without a select where every lane of the
+    // group takes the record; the longer terms are written once.
+    constexpr bool TWO_FORMS = LAW == NBODY_LAW_PLUMMER && !QUAD;
     while (top > 0) {
         --top;
         const uint4 e = stack[top];
-        const uint32_t first = __builtin_amdgcn_readfirstlane(e.x);
-        const uint32_t cnt = __builtin_amdgcn_readfirstlane(e.y);
-        // (readfirstlane returns int: go through uint32_t, or the low half sign-extends over the high)
+        uint32_t first = __builtin_amdgcn_readfirstlane(e.x);
+        uint32_t cnt = __builtin_amdgcn_readfirstlane(e.y);
         const uint32_t mlo = (uint32_t)__builtin_amdgcn_readfirstlane(e.z);
         const uint32_t mhi = (uint32_t)__builtin_amdgcn_readfirstlane(e.w);
         const unsigned long long mask = ((unsigned long long)mhi << 32) | (unsigned long long)mlo;
-        // with quadrupoles the moments ride along with the records: half the batch, same registers
-        constexpr int BATCH = QUAD ? WALK_BATCH / 2 : WALK_BATCH;
-        for (uint32_t b0 = 0; b0 < cnt; b0 += BATCH) {
-            const uint32_t nb = min((uint32_t)BATCH, cnt - b0);
-            // All records of the batch are fetched before the first use, from consecutive
-            // addresses whether the group has that many or not (the array is padded).
-            QNode c[BATCH];
-            QMoment qm[QUAD ? BATCH : 1];
-            const QNode* group = q + (first + b0);
+        if (cnt > (uint32_t)BATCH) {  // the rest of a long group (a leaf list) goes back where it came from
+            stack[top] = make_uint4(first + BATCH, cnt - BATCH, mlo, mhi);
+            ++top;
+            cnt = BATCH;
+        }
+        // All records of the batch are fetched before the first use, from consecutive addresses
+        // whether the group has that many or not (the array is padded).
+        QNode c[BATCH];
+        QMoment qm[QUAD ? BATCH : 1];
+        const QNode* group = q + first;
 #pragma unroll
-            for (int k = 0; k < BATCH; ++k) c[k] = group[k];
-            if (QUAD) {
-                const QMoment* gq = reinterpret_cast<const QMoment*>(quad) + (first + b0);
+        for (int k = 0; k < BATCH; ++k) c[k] = group[k];
+        if (QUAD) {
+            const QMoment* gq = reinterpret_cast<const QMoment*>(quad) + first;
 #pragma unroll
-                for (int k = 0; k < BATCH; ++k) qm[k] = gq[k];
-            }
+            for (int k = 0; k < BATCH; ++k) qm[k] = gq[k];
+        }
 #pragma unroll
-            for (int k = 0; k < BATCH; ++k) pin_record(c[k]);
-            if (QUAD) {
+        for (int k = 0; k < BATCH; ++k) pin_record(c[k]);
+        if (QUAD) {
 #pragma unroll
-                for (int k = 0; k < BATCH; ++k) pin_moment(qm[k]);
-            }
-            if (top + BATCH > WALK_STACK) {
-                if (lane == 0) *err_flag = 2;
-                top = 0;
-                break;
-            }
-#pragma unroll
-            for (int k = 0; k < BATCH; ++k) {
-                if ((uint32_t)k >= nb) break;
+            for (int k = 0; k < BATCH; ++k) pin_moment(qm[k]);
+        }
+        __builtin_assume(cnt >= 1);
+        if (COUNT) n_wave += cnt;
+        // Inside this branch EXEC is the group's lane set.  The stack pointer is advanced by those
+        // lanes only (to the compiler it is a per-lane value there) and read back from one of them.
+        int top_v = top;
+        if (__builtin_amdgcn_inverse_ballot_w64(mask)) {
+            auto rec = [&](const int k) __attribute__((always_inline)) {
                 const QNode nd = c[k];
-                if (COUNT) {
-                    n_wave += (lane == 0);
-                    n_visit += __builtin_amdgcn_inverse_ballot_w64(mask);
-                }
+                if (COUNT) ++n_visit;
                 const float dx = nd.cx - t.x, dy = nd.cy - t.y, dz = nd.cz - t.z;
                 // PLUMMER: the softened squared distance, which the thresholds are prepared for
                 const float r2 = LAW == NBODY_LAW_PLUMMER ? fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, eps2)))
                                                           : fmaf(dx, dx, fmaf(dy, dy, dz * dz));
-                // Lanes that take this node as one source.  src/nbodybh.wgsl:104-106 by the node's
-                // squared-distance thresholds; a LEAFBODY record (a direct interaction,
-                // src/nbodybh.wgsl:76-102) carries thresholds below zero, which every lane passes.
-                unsigned long long take = mask & lanes(r2 > nd.r2_accept);
-                const unsigned long long rest = mask & ~take;
-                if (rest) {
-                    // not clearly accepted: clearly to be opened, or inside the band between the
-                    // thresholds, where the reference's own expression decides
-                    unsigned long long open = rest;
-                    const unsigned long long unsure = rest & ~lanes(r2 < nd.r2_open);
-                    if (unsure) {
-                        const float rg = range[first + b0 + k];
-                        const float rr = sqrtf(((dx * dx) + (dy * dy)) + (dz * dz));  // distance(pos, com)
-                        const unsigned long long yes = unsure & lanes((rg / rr) < theta);
-                        take |= yes;
-                        open &= ~yes;
-                    }
-                    if (open) {
-                        // INTERIOR: its children; LEAFLIST: its members (LEAFBODY records, src/nbodybh.wgsl:137-146)
-                        stack[top] = make_uint4(nd.first, qn_count(nd), (uint32_t)open, (uint32_t)(open >> 32));
-                        ++top;
-                        if (COUNT) max_top = max(max_top, (uint32_t)top);
-                    }
-                }
-                if (COUNT) {
-                    if (qn_type(nd) == NBODY_NODE_LEAFBODY) n_leaf += __builtin_amdgcn_inverse_ballot_w64(take);
-                    else n_agg += __builtin_amdgcn_inverse_ballot_w64(take);
-                }
-                // The cheap PLUMMER term is evaluated for every record: testing for "no lane takes
-                // it" costs more scalar instructions than the ten vector ones it sometimes saves.
-                if (QUAD || LAW != NBODY_LAW_PLUMMER ? take != 0 : true) {
-                    // every lane evaluates the term; lanes that do not take it add zero
+                // src/nbodybh.wgsl:104-106 by the node's squared-distance thresholds; a LEAFBODY record
+                // (a direct interaction, src/nbodybh.wgsl:76-102) carries thresholds below zero.
+                // `off`: lanes of the group that do not take the record (select) -- none where !select
+                auto term = [&](bool select, unsigned long long off) {
                     float ri = 0.0f;  // QUAD (PLUMMER law only): 1/R shared by the monopole and quadrupole terms
                     float sc;
                     if (LAW == NBODY_LAW_PLUMMER) {  // src/nbody.wgsl:56-65; r2 is softened already
@@ -921,7 +892,8 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(7,
                     } else {
                         sc = pair_scale<LAW, WALK_PRECISE>(t, dx, dy, dz, r2, nd.mass, eps2);
                     }
-                    const float w = __builtin_amdgcn_inverse_ballot_w64(take) ? sc : 0.0f;
+                    const bool skip = select && __builtin_amdgcn_inverse_ballot_w64(off);
+                    const float w = skip ? 0.0f : sc;
                     ax = fmaf(w, dx, ax);
                     ay = fmaf(w, dy, ay);
                     az = fmaf(w, dz, az);
@@ -936,22 +908,75 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(7,
                         const float uy = fmaf(qxy, dx, fmaf(qyy, dy, qyz * dz));
                         const float uz = fmaf(qxz, dx, fmaf(qyz, dy, qzz * dz));
                         const float dqd = fmaf(dx, ux, fmaf(dy, uy, dz * uz));
-                        const bool on = __builtin_amdgcn_inverse_ballot_w64(take);
-                        const float c1 = on ? -ri5 : 0.0f, c2 = on ? 2.5f * dqd * ri7 : 0.0f;
+                        const float c1 = skip ? 0.0f : -ri5, c2 = skip ? 0.0f : 2.5f * dqd * ri7;
                         ax = fmaf(c1, ux, fmaf(c2, dx, ax));
                         ay = fmaf(c1, uy, fmaf(c2, dy, ay));
                         az = fmaf(c1, uz, fmaf(c2, dz, az));
                     }
+                };
+                // The group's lanes that do not clearly accept the record: src/nbodybh.wgsl:104-106 by
+                // the node's squared-distance thresholds; a LEAFBODY record (a direct interaction,
+                // src/nbodybh.wgsl:76-102) carries thresholds below zero, which every lane passes.
+                const unsigned long long rest = __ballot(!(r2 > nd.r2_accept));
+                // The lanes among them that open it: clearly to be opened, or inside the band between
+                // the thresholds, where the reference's own expression decides.
+                auto opening = [&]() {
+                    unsigned long long open = rest;
+                    const unsigned long long unsure = rest & lanes(!(r2 < nd.r2_open));
+                    if (unsure) {
+                        const float rg = range[first + k];
+                        const float rr = sqrtf(((dx * dx) + (dy * dy)) + (dz * dz));  // distance(pos, com)
+                        open &= ~(unsure & lanes((rg / rr) < theta));
+                    }
+                    if (open) {
+                        // INTERIOR: its children; LEAFLIST: its members (LEAFBODY records, src/nbodybh.wgsl:137-146)
+                        if (top_v < WALK_STACK) {
+                            stack[top_v] = make_uint4(nd.first, qn_count(nd), (uint32_t)open, (uint32_t)(open >> 32));
+                            ++top_v;
+                        } else {
+                            *err_flag = 2;  // (a tree deeper than any the build makes: uploaded)
+                        }
+                    }
+                    return open;
+                };
+                auto count_taken = [&](unsigned long long open) {
+                    if (COUNT && !__builtin_amdgcn_inverse_ballot_w64(open)) {
+                        if (qn_type(nd) == NBODY_NODE_LEAFBODY) ++n_leaf;
+                        else ++n_agg;
+                    }
+                };
+                if (TWO_FORMS) {
+                    // (the term is evaluated whether or not a lane takes it: the test costs more)
+                    if (rest == 0) {
+                        count_taken(0ull);
+                        term(false, 0ull);
+                    } else {
+                        const unsigned long long open = opening();
+                        count_taken(open);
+                        term(true, open);
+                    }
+                } else {
+                    unsigned long long open = 0;
+                    if (rest != 0) open = opening();
+                    count_taken(open);
+                    if (open != mask) term(true, open);
                 }
+            };
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k) {
+                if ((uint32_t)k >= cnt) break;
+                rec(k);
             }
         }
+        top = __builtin_amdgcn_readlane(top_v, (int)__builtin_ctzll(mask));
+        if (COUNT) max_top = max(max_top, (uint32_t)top);  // pushes only grow the stack within a batch
     }
     if (valid) acc_out[out_by_rank ? i_begin + r : b] = make_float4(G * ax, G * ay, G * az, 0.0f);
     if (COUNT) {
         atomicAdd(&counters[0], (unsigned long long)n_visit);
         atomicAdd(&counters[1], (unsigned long long)n_leaf);
         atomicAdd(&counters[2], (unsigned long long)n_agg);
-        atomicAdd(&counters[3], (unsigned long long)n_wave);
+        if (lane == 0) atomicAdd(&counters[3], (unsigned long long)n_wave);
         atomicMax(&counters[4], (unsigned long long)max_top);
     }
 }
@@ -1020,11 +1045,11 @@ void launch_walk(nbody_ctx* ctx, Octree* T, const uint32_t* order, uint32_t m, c
                        vel, acc_out, ctx->cfg.G, ctx->cfg.eps2, ctx->cfg.theta, T->range,                                 \
                        (unsigned long long*)T->walk_counters, T->err_flag, out_by_rank, T->quad)
     if (ctx->counting) {
-        if (quad) NB_WALK(true, true);
-        else NB_WALK(true, false);
+        if (quad) { NB_WALK(true, true); }
+        else { NB_WALK(true, false); }
     } else {
-        if (quad) NB_WALK(false, true);
-        else NB_WALK(false, false);
+        if (quad) { NB_WALK(false, true); }
+        else { NB_WALK(false, false); }
     }
 #undef NB_WALK
 }

@@ -7,6 +7,7 @@
 //   E: D with the v_rsq_f32 replaced by a v_mul_f32 (what the one transcendental costs in this mix)
 //   F, G: D for four / eight records at a time, pass by pass (independent chains interleaved, the
 //         transcendentals back to back)
+//   H..L: two records per packed instruction (record fields of a pair in consecutive scalar registers)
 //   hipcc --offload-arch=gfx950 -O3 -o ubench_walkmix ubench_walkmix.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -99,6 +100,84 @@ __global__ __launch_bounds__(64) void k_mix(float* out, int trips, float seed, f
     if (ax + ay + az == 123.456f) out[0] = ax;
 }
 
+
+// Two records per instruction: operands %0..%2 packed accumulators, %3 {tx,ty}, %4 {tz,eps2} (v pairs);
+// %5 cx pair, %6 cy pair, %7 cz pair, %8 mass pair (s pairs), %9 %10 thresholds (s)
+#define PAIR_V1(a) \
+    "v_pk_add_f32 v[" #a "0:" #a "1], %5, %3 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t" \
+    "v_pk_add_f32 v[" #a "2:" #a "3], %6, %3 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t" \
+    "v_pk_add_f32 v[" #a "4:" #a "5], %7, %4 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t" \
+    "v_pk_fma_f32 v[" #a "6:" #a "7], v[" #a "4:" #a "5], v[" #a "4:" #a "5], %4 op_sel:[0,0,1] op_sel_hi:[1,1,1]\n\t" \
+    "v_pk_fma_f32 v[" #a "6:" #a "7], v[" #a "2:" #a "3], v[" #a "2:" #a "3], v[" #a "6:" #a "7]\n\t" \
+    "v_pk_fma_f32 v[" #a "6:" #a "7], v[" #a "0:" #a "1], v[" #a "0:" #a "1], v[" #a "6:" #a "7]\n\t"
+#define PAIR_CMP(a, sa, sb) \
+    "v_cmp_lt_f32 " sa ", %9, v" #a "6\n\tv_cmp_lt_f32 " sb ", %10, v" #a "7\n\t"
+#define PAIR_RSQ(a) "v_rsq_f32 v" #a "6, v" #a "6\n\tv_rsq_f32 v" #a "7, v" #a "7\n\t"
+#define PAIR_SC(a) \
+    "v_pk_mul_f32 v[" #a "8:" #a "9], %8, v[" #a "6:" #a "7]\n\t" \
+    "v_pk_mul_f32 v[" #a "6:" #a "7], v[" #a "6:" #a "7], v[" #a "6:" #a "7]\n\t" \
+    "v_pk_mul_f32 v[" #a "6:" #a "7], v[" #a "8:" #a "9], v[" #a "6:" #a "7]\n\t"
+#define PAIR_SEL(a, sa, sb) "v_cndmask_b32 v" #a "6, 0, v" #a "6, " sa "\n\tv_cndmask_b32 v" #a "7, 0, v" #a "7, " sb "\n\t"
+#define PAIR_ACC(a) \
+    "v_pk_fma_f32 %0, v[" #a "6:" #a "7], v[" #a "0:" #a "1], %0\n\t" \
+    "v_pk_fma_f32 %1, v[" #a "6:" #a "7], v[" #a "2:" #a "3], %1\n\t" \
+    "v_pk_fma_f32 %2, v[" #a "6:" #a "7], v[" #a "4:" #a "5], %2\n\t"
+#define PAIR_H PAIR_V1(2) PAIR_CMP(2, "s[20:21]", "s[22:23]") PAIR_RSQ(2) PAIR_SC(2) PAIR_ACC(2)
+#define PAIR_I PAIR_V1(2) PAIR_CMP(2, "s[20:21]", "s[22:23]") PAIR_RSQ(2) PAIR_SC(2) PAIR_SEL(2, "s[20:21]", "s[22:23]") PAIR_ACC(2)
+#define PAIR_J PAIR_V1(2) PAIR_V1(3) PAIR_CMP(2, "s[20:21]", "s[22:23]") PAIR_CMP(3, "s[26:27]", "s[28:29]") PAIR_RSQ(2) PAIR_RSQ(3) \
+    PAIR_SC(2) PAIR_SC(3) PAIR_ACC(2) PAIR_ACC(3)
+#define PAIR_K PAIR_V1(2) PAIR_V1(3) PAIR_V1(4) PAIR_V1(5) PAIR_CMP(2, "s[20:21]", "s[22:23]") PAIR_CMP(3, "s[26:27]", "s[28:29]") \
+    PAIR_CMP(4, "s[30:31]", "s[32:33]") PAIR_CMP(5, "s[34:35]", "s[36:37]") PAIR_RSQ(2) PAIR_RSQ(3) PAIR_RSQ(4) PAIR_RSQ(5) \
+    PAIR_SC(2) PAIR_SC(3) PAIR_SC(4) PAIR_SC(5) PAIR_ACC(2) PAIR_ACC(3) PAIR_ACC(4) PAIR_ACC(5)
+// H without the transcendental (what the two v_rsq_f32 cost in the packed mix)
+#define PAIR_L PAIR_V1(2) PAIR_CMP(2, "s[20:21]", "s[22:23]") "v_mul_f32 v26, v26, v26\n\tv_mul_f32 v27, v27, v27\n\t" PAIR_SC(2) PAIR_ACC(2)
+typedef float f2 __attribute__((ext_vector_type(2)));
+template <int KIND>
+__global__ __launch_bounds__(64) void k_pair(float* out, int trips, float seed, f2 cx, f2 cy, f2 cz, f2 m, float thr0, float thr1, float eps2) {
+    f2 ax = {0, 0}, ay = {0, 0}, az = {0, 0};
+    const f2 txy = {seed + threadIdx.x, seed * 2 + threadIdx.x}, tze = {seed * 3, eps2};
+    for (int t = 0; t < trips; ++t) {
+#define POPS : "+v"(ax), "+v"(ay), "+v"(az) : "v"(txy), "v"(tze), "s"(cx), "s"(cy), "s"(cz), "s"(m), "s"(thr0), "s"(thr1) \
+            : "s20", "s21", "s22", "s23", "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35", "s36", "s37", \
+              "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", \
+              "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59"
+        if (KIND == 0) asm volatile(PAIR_H PAIR_H PAIR_H PAIR_H POPS);
+        if (KIND == 1) asm volatile(PAIR_I PAIR_I PAIR_I PAIR_I POPS);
+        if (KIND == 2) asm volatile(PAIR_J PAIR_J POPS);
+        if (KIND == 3) asm volatile(PAIR_K POPS);
+        if (KIND == 4) asm volatile(PAIR_L PAIR_L PAIR_L PAIR_L POPS);
+    }
+    if (ax.x + ay.x + az.x + ax.y + ay.y + az.y == 123.456f) out[0] = ax.x;
+}
+template <int KIND>
+int run_pair(const char* name) {
+    float* out;
+    CHECK(hipMalloc(&out, 4));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const int simds = prop.multiProcessorCount * 4;
+    const f2 cx = {3.f, 3.5f}, cy = {4.f, 4.5f}, cz = {5.f, 5.5f}, m = {1.f, 2.f};
+    for (int wps : {1, 2, 4, 6, 7, 8}) {
+        const int blocks = simds * wps, trips = 40000 / wps;
+        const size_t lds = (size_t)(160 * 1024) / (4 * wps) - 512;
+        k_pair<KIND><<<blocks, 64, lds>>>(out, 10, 1.0f, cx, cy, cz, m, 0.5f, 0.6f, 1.f);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipEventRecord(e0));
+        k_pair<KIND><<<blocks, 64, lds>>>(out, trips, 1.0f, cx, cy, cz, m, 0.5f, 0.6f, 1.f);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        const double cyc = ms * 1e-3 * 2.4e9 / ((double)wps * trips * 8);
+        printf("%-52s waves/SIMD=%d  %8.3f ms  %6.1f cycles per record per SIMD (at 2.4 GHz)\n", name, wps, ms, cyc);
+    }
+    CHECK(hipFree(out));
+    return 0;
+}
+
 template <int KIND>
 int run(const char* name) {
     float* out;
@@ -136,5 +215,10 @@ int main() {
     run<4>("E 15 VALU, v_rsq_f32 replaced by v_mul_f32");
     run<5>("F 15 VALU, four records pass by pass");
     run<6>("G 15 VALU, eight records pass by pass");
+    run_pair<0>("H two records packed (12 pk, 2 cmp, 2 rsq)");
+    run_pair<1>("I H with two selects");
+    run_pair<2>("J H for two pairs pass by pass");
+    run_pair<3>("K H for four pairs pass by pass");
+    run_pair<4>("L H with v_rsq_f32 replaced by v_mul_f32");
     return 0;
 }

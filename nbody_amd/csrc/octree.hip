@@ -103,6 +103,7 @@ struct Octree {
     // nodes
     QNode* nodes = nullptr;
     void* pairs = nullptr;           // the same records, two side by side (the PLUMMER traversal's form)
+    bool pairs_valid = false;        // ... made from the present tree (on the first traversal that wants them)
     float4* bmin = nullptr;          // bounding box of the bodies below each node
     float4* bmax = nullptr;
     float* range = nullptr;          // longest side of that box (src/octree_maxdepth.rs:101)
@@ -1317,7 +1318,16 @@ void launch_walk(nbody_ctx* ctx, Octree* T, const uint32_t* order, uint32_t m, c
     const bool ordered = grid.x <= 8 * ORDER_MAX && grid.x >= 64;
     const uint32_t* perm = ordered && T->perm_nblk == grid.x && T->perm_order == order ? T->wave_perm : nullptr;
     uint32_t* cost = ordered ? T->wave_cost : nullptr;
-    if (LAW == NBODY_LAW_PLUMMER && !quad && !getenv("NBODY_WALK_SINGLE")) {
+    // The pair form costs a pass over the records (they are written in both alignments): taken when
+    // this traversal covers at least half the bodies, or the pairs of this tree exist already.  A
+    // rank of a many-GPU run, walking an eighth of the bodies of a replicated tree, keeps the
+    // one-record kernel.
+    static const bool no_pairs = getenv("NBODY_WALK_SINGLE") != nullptr;
+    if (LAW == NBODY_LAW_PLUMMER && !quad && !no_pairs && (T->pairs_valid || 2 * (uint64_t)m >= T->n)) {
+        if (!T->pairs_valid) {
+            pairify(ctx, T);
+            T->pairs_valid = true;
+        }
 #define NB_WALK_PAIR(COUNT)                                                                                               \
     hipLaunchKernelGGL((k_walk_pair<COUNT>), grid, dim3(WALK_THREADS), 0, ctx->stream, (const QPair*)T->pairs, (uint32_t)pair_half(T->cap_nodes), order, m, i_begin, posm,  \
                        acc_out, ctx->cfg.G, ctx->cfg.eps2, ctx->cfg.theta, T->range, (unsigned long long*)T->walk_counters, \
@@ -1491,7 +1501,7 @@ int nb_tree_build(nbody_ctx* ctx, const float4* posm_in) {
                                ctx->cfg.leaflist_mode);
         }
     }
-    pairify(ctx, T);
+    T->pairs_valid = false;
     nb_time_end(ctx, 2);
     NB_HIP(ctx, hipGetLastError());
     T->have_tree = true;
@@ -1676,7 +1686,7 @@ int nb_tree_upload(nbody_ctx* ctx, const nbody_octree_node* host_nodes, uint64_t
     hipLaunchKernelGGL(k_import, dim3((cnt + 255) / 256), dim3(256), 0, ctx->stream, T->export_buf, cnt, T->nodes, T->bmin,
                        T->bmax, T->range, mac_scale(ctx), T->err_flag);
     T->n_nodes = kept;
-    pairify(ctx, T);
+    T->pairs_valid = false;
     NB_HIP(ctx, hipGetLastError());
     NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     T->have_tree = true;

@@ -102,8 +102,6 @@ struct Octree {
     hipEvent_t lvl_ready = nullptr;   // the copy into it has completed
     // nodes
     QNode* nodes = nullptr;
-    void* pairs = nullptr;           // the same records, two side by side (the PLUMMER traversal's form)
-    bool pairs_valid = false;        // ... made from the present tree (on the first traversal that wants them)
     float4* bmin = nullptr;          // bounding box of the bodies below each node
     float4* bmax = nullptr;
     float* range = nullptr;          // longest side of that box (src/octree_maxdepth.rs:101)
@@ -995,221 +993,6 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(7,
     }
 }
 
-// ---- traversal, two records per instruction (PLUMMER law, monopoles) ---------------------------
-// The same traversal with two consecutive records side by side: the two records' values of one
-// field lie in consecutive scalar registers, which is the 64-bit operand of a packed instruction,
-// so separation, squared distance, the scale factor and the accumulation of two records are twelve
-// v_pk_*_f32 against a broadcast target (measured: 37 SIMD cycles per record against 60 for the
-// one-record sequence, the two v_rsq_f32 almost hidden behind the packed work).
-// Groups start at even and at odd record numbers alike, so the pairs exist in both alignments:
-// pair array `f & 1` holds (f, f + 1) at index f / 2, and a group [first, first + count) reads the
-// consecutive pairs first / 2 ... of the array of its own parity.  The high half of the last pair
-// of an odd group belongs to the next group: it is carried through the packed instructions and its
-// factor set to zero.
-typedef float f2 __attribute__((ext_vector_type(2)));
-struct QPair {
-    f2 cx, cy, cz, mass;
-    f2 r2_open, r2_accept;
-    uint32_t first[2];
-    uint32_t count_type[2];
-};
-static_assert(sizeof(QPair) == 64, "pair record layout");
-constexpr int WALK_PBATCH = 4;      // pairs fetched together; each pair array is padded by as many
-constexpr float QP_FAR = 1.0e18f;   // a null record's coordinates: r^2 ~ 3e36 is finite, its rsq^3 times mass 0 is 0
-
-__host__ __device__ inline uint64_t pair_half(uint64_t cap_nodes) { return cap_nodes / 2 + 2 + WALK_PBATCH; }  // pairs per alignment
-
-__device__ __forceinline__ void pin_pair(const QPair& nd) {
-    asm volatile("" ::"s"(nd.cx), "s"(nd.cy), "s"(nd.cz), "s"(nd.mass), "s"(nd.r2_open), "s"(nd.r2_accept), "s"(nd.first[0]),
-                 "s"(nd.first[1]), "s"(nd.count_type[0]), "s"(nd.count_type[1]));
-}
-
-// Thread f writes the pair (f, f + 1) into the array of its parity; records beyond the last are null.
-__global__ void k_pairify(const QNode* __restrict__ nodes, uint32_t n_nodes, uint32_t n_out, uint32_t half, QPair* __restrict__ out) {
-    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= n_out) return;
-    QNode a, b;
-    a.cx = a.cy = a.cz = QP_FAR; a.mass = 0.0f; a.r2_open = a.r2_accept = QN_ALWAYS; a.first = 0; a.count_type = 0;
-    b = a;
-    if (f < n_nodes) a = nodes[f];
-    if (f + 1 < n_nodes) b = nodes[f + 1];
-    QPair o;
-    o.cx = f2{a.cx, b.cx}; o.cy = f2{a.cy, b.cy}; o.cz = f2{a.cz, b.cz}; o.mass = f2{a.mass, b.mass};
-    o.r2_open = f2{a.r2_open, b.r2_open}; o.r2_accept = f2{a.r2_accept, b.r2_accept};
-    // where a record's children start, as the traversal addresses them: the pair index of that group
-    o.first[0] = (a.first & 1u) * half + (a.first >> 1);
-    o.first[1] = (b.first & 1u) * half + (b.first >> 1);
-    o.count_type[0] = a.count_type; o.count_type[1] = b.count_type;
-    out[(size_t)(f & 1u) * half + (f >> 1)] = o;
-}
-
-template <bool COUNT>
-__global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_walk_pair(
-    const QPair* __restrict__ qp, uint32_t half, const uint32_t* __restrict__ order, uint32_t m, uint32_t i_begin,
-    const float4* __restrict__ posm, float4* __restrict__ acc_out, float G, float eps2, float theta,
-    const float* __restrict__ range, unsigned long long* __restrict__ counters, uint32_t* __restrict__ err_flag,
-    int out_by_rank, const uint32_t* __restrict__ perm, uint32_t* __restrict__ wave_cost) {
-    __shared__ uint4 stack[WALK_STACK];  // {pair index of the group's first record, count, mask.lo, mask.hi}
-    const int lane = threadIdx.x;
-    const uint32_t nblk = gridDim.x, q8 = nblk / 8, r8 = nblk % 8;
-    const uint32_t xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
-    const uint32_t blk = perm ? perm[blockIdx.x] : xcd * q8 + min(xcd, r8) + slot;
-    const uint32_t r = blk * WALK_THREADS + lane;
-    const bool valid = r < m;
-    const uint32_t b = valid ? (order ? order[r] : i_begin + r) : 0u;
-    const float4 tp = posm[b];
-    f2 soft = {eps2, eps2};
-    uint32_t half_v = half;
-    asm volatile("" : "+v"(soft), "+v"(half_v));  // (kept in vector registers: the scalar ones are full of records)
-    f2 ax = {0.0f, 0.0f}, ay = {0.0f, 0.0f}, az = {0.0f, 0.0f};  // even and odd records' sums
-    uint32_t n_visit = 0, n_leaf = 0, n_agg = 0, n_wave = 0, max_top = 0;
-    int top = 0;
-    const unsigned long long all = __ballot(valid);
-    if (all) {
-        stack[0] = make_uint4(0u, 1u, (uint32_t)all, (uint32_t)(all >> 32));  // the root as a one-node group
-        top = 1;
-    }
-    while (top > 0) {
-        --top;
-        const uint4 e = stack[top];
-        const uint32_t pidx = __builtin_amdgcn_readfirstlane(e.x);
-        uint32_t cnt = __builtin_amdgcn_readfirstlane(e.y);
-        const uint32_t mlo = (uint32_t)__builtin_amdgcn_readfirstlane(e.z);
-        const uint32_t mhi = (uint32_t)__builtin_amdgcn_readfirstlane(e.w);
-        const unsigned long long mask = ((unsigned long long)mhi << 32) | (unsigned long long)mlo;
-        if (cnt > 2u * WALK_PBATCH) {  // the rest of a long group (a leaf list) goes back where it came from
-            stack[top] = make_uint4(pidx + WALK_PBATCH, cnt - 2u * WALK_PBATCH, mlo, mhi);
-            ++top;
-            cnt = 2u * WALK_PBATCH;
-        }
-        QPair c[WALK_PBATCH];
-        const QPair* group = qp + pidx;
-#pragma unroll
-        for (int k = 0; k < WALK_PBATCH; ++k) c[k] = group[k];
-#pragma unroll
-        for (int k = 0; k < WALK_PBATCH; ++k) pin_pair(c[k]);
-        __builtin_assume(cnt >= 1);
-        n_wave += cnt;
-        int top_v = top;
-        if (__builtin_amdgcn_inverse_ballot_w64(mask)) {
-            // Lanes of the group that open record h of pair j (they did not clearly accept it: `rest`), with
-            // the push of its children; the others take it as a source.
-            auto opening = [&](const int j, const int h, unsigned long long rest, float r2h, float ddx, float ddy, float ddz) {
-                const QPair& nd = c[j];
-                unsigned long long open = rest;
-                const unsigned long long unsure = rest & lanes(!(r2h < (h ? nd.r2_open.y : nd.r2_open.x)));
-                if (unsure) {  // inside the band between the thresholds the reference's own expression decides
-                    const uint32_t hv = __builtin_amdgcn_readfirstlane(half_v);
-                    const uint32_t rec_id = (pidx >= hv ? 2u * (pidx - hv) + 1u : 2u * pidx) + 2u * (uint32_t)j + (uint32_t)h;
-                    const float rg = range[rec_id];
-                    const float rr = sqrtf(((ddx * ddx) + (ddy * ddy)) + (ddz * ddz));  // distance(pos, com)
-                    open &= ~(unsure & lanes((rg / rr) < theta));
-                }
-                if (open) {
-                    // INTERIOR: its children; LEAFLIST: its members (LEAFBODY records, src/nbodybh.wgsl:137-146)
-                    if (top_v < WALK_STACK) {
-                        stack[top_v] = make_uint4(nd.first[h], nd.count_type[h] & 0x3fffffffu, (uint32_t)open, (uint32_t)(open >> 32));
-                        ++top_v;
-                    } else {
-                        *err_flag = 2;  // (a tree deeper than any the build makes: uploaded)
-                    }
-                }
-                return open;
-            };
-            auto count_taken = [&](const int j, const int h, unsigned long long open) {
-                if (COUNT) {
-                    ++n_visit;
-                    if (!__builtin_amdgcn_inverse_ballot_w64(open)) {
-                        if ((c[j].count_type[h] >> 30) == NBODY_NODE_LEAFBODY) ++n_leaf;
-                        else ++n_agg;
-                    }
-                }
-            };
-            // One step: the first V (1..4) records of the pairs j and j + 1.  Halves beyond V belong to the
-            // next group: they ride through the packed instructions and their factor is set to zero.
-            auto step = [&](const int j, const int V) __attribute__((always_inline)) {
-                const QPair na = c[j], nb = c[V > 2 ? j + 1 : j];
-                const f2 dxa = na.cx - tp.x, dya = na.cy - tp.y, dza = na.cz - tp.z;
-                // the softened squared distance, which the thresholds are prepared for
-                const f2 r2a = __builtin_elementwise_fma(dxa, dxa, __builtin_elementwise_fma(dya, dya, __builtin_elementwise_fma(dza, dza, soft)));
-                f2 dxb = dxa, dyb = dya, dzb = dza, r2b = r2a;
-                if (V > 2) {
-                    dxb = nb.cx - tp.x; dyb = nb.cy - tp.y; dzb = nb.cz - tp.z;
-                    r2b = __builtin_elementwise_fma(dxb, dxb, __builtin_elementwise_fma(dyb, dyb, __builtin_elementwise_fma(dzb, dzb, soft)));
-                }
-                // lanes of the group that do not clearly accept each record (src/nbodybh.wgsl:104-106 by the
-                // node's squared-distance thresholds; LEAFBODY records carry thresholds below zero)
-                const unsigned long long rest0 = __ballot(!(r2a.x > na.r2_accept.x));
-                const unsigned long long rest1 = V > 1 ? __ballot(!(r2a.y > na.r2_accept.y)) : 0ull;
-                const unsigned long long rest2 = V > 2 ? __ballot(!(r2b.x > nb.r2_accept.x)) : 0ull;
-                const unsigned long long rest3 = V > 3 ? __ballot(!(r2b.y > nb.r2_accept.y)) : 0ull;
-                f2 ria, rib;
-                ria.x = __builtin_amdgcn_rsqf(r2a.x);
-                ria.y = __builtin_amdgcn_rsqf(r2a.y);
-                f2 sca = (na.mass * ria) * (ria * ria), scb = sca;  // src/nbody.wgsl:56-65
-                if (V == 1) sca.y = 0.0f;
-                if (V > 2) {
-                    rib.x = __builtin_amdgcn_rsqf(r2b.x);
-                    rib.y = __builtin_amdgcn_rsqf(r2b.y);
-                    scb = (nb.mass * rib) * (rib * rib);
-                    if (V == 3) scb.y = 0.0f;
-                }
-                unsigned long long open0 = 0, open1 = 0, open2 = 0, open3 = 0;
-                if ((rest0 | rest1 | rest2 | rest3) != 0) {
-                    if (rest0) open0 = opening(j, 0, rest0, r2a.x, dxa.x, dya.x, dza.x);
-                    if (V > 1 && rest1) open1 = opening(j, 1, rest1, r2a.y, dxa.y, dya.y, dza.y);
-                    if (V > 2 && rest2) open2 = opening(j + 1, 0, rest2, r2b.x, dxb.x, dyb.x, dzb.x);
-                    if (V > 3 && rest3) open3 = opening(j + 1, 1, rest3, r2b.y, dxb.y, dyb.y, dzb.y);
-                    sca.x = __builtin_amdgcn_inverse_ballot_w64(open0) ? 0.0f : sca.x;
-                    if (V > 1) sca.y = __builtin_amdgcn_inverse_ballot_w64(open1) ? 0.0f : sca.y;
-                    if (V > 2) scb.x = __builtin_amdgcn_inverse_ballot_w64(open2) ? 0.0f : scb.x;
-                    if (V > 3) scb.y = __builtin_amdgcn_inverse_ballot_w64(open3) ? 0.0f : scb.y;
-                }
-                if (COUNT) {
-                    count_taken(j, 0, open0);
-                    if (V > 1) count_taken(j, 1, open1);
-                    if (V > 2) count_taken(j + 1, 0, open2);
-                    if (V > 3) count_taken(j + 1, 1, open3);
-                }
-                ax = __builtin_elementwise_fma(sca, dxa, ax);
-                ay = __builtin_elementwise_fma(sca, dya, ay);
-                az = __builtin_elementwise_fma(sca, dza, az);
-                if (V > 2) {
-                    ax = __builtin_elementwise_fma(scb, dxb, ax);
-                    ay = __builtin_elementwise_fma(scb, dyb, ay);
-                    az = __builtin_elementwise_fma(scb, dzb, az);
-                }
-            };
-            static_assert(WALK_PBATCH == 4, "written out for two steps of two pairs");
-            do {
-                if (cnt < 4u) {
-                    if (cnt == 3u) step(0, 3);
-                    else if (cnt == 2u) step(0, 2);
-                    else step(0, 1);
-                    break;
-                }
-                step(0, 4);
-                if (cnt == 4u) break;
-                if (cnt == 8u) step(2, 4);
-                else if (cnt == 7u) step(2, 3);
-                else if (cnt == 6u) step(2, 2);
-                else step(2, 1);
-            } while (false);
-        }
-        top = __builtin_amdgcn_readlane(top_v, (int)__builtin_ctzll(mask));
-        if (COUNT) max_top = max(max_top, (uint32_t)top);
-    }
-    if (valid) acc_out[out_by_rank ? i_begin + r : b] = make_float4(G * (ax.x + ax.y), G * (ay.x + ay.y), G * (az.x + az.y), 0.0f);
-    if (wave_cost && lane == 0) wave_cost[blk] = n_wave;
-    if (COUNT) {
-        atomicAdd(&counters[0], (unsigned long long)n_visit);
-        atomicAdd(&counters[1], (unsigned long long)n_leaf);
-        atomicAdd(&counters[2], (unsigned long long)n_agg);
-        if (lane == 0) atomicAdd(&counters[3], (unsigned long long)n_wave);
-        atomicMax(&counters[4], (unsigned long long)max_top);
-    }
-}
-
 // Launch order for the next traversal of the same targets: workgroup b runs on XCD b % 8 and is the
 // (b / 8)-th that XCD starts; each XCD's contiguous share of the wavefronts is sorted by the node
 // visits they made last time, longest first, so that the wavefronts still running when the others
@@ -1259,7 +1042,7 @@ int ensure_nodes(nbody_ctx* ctx, Octree* T, uint64_t need) {
     if (need <= T->cap_nodes) return NBODY_OK;
     uint64_t cap = std::max<uint64_t>(need + need / 4 + 1024, 2 * T->n + 1024);
     if (cap > 0xfffffff0ull) return nb_fail(ctx, NBODY_ERR_CAPACITY, "octree needs more than 2^32 nodes");
-    void** arrays[] = {(void**)&T->nodes, (void**)&T->pairs, (void**)&T->node_head, (void**)&T->bmin, (void**)&T->bmax, (void**)&T->range, (void**)&T->quad};
+    void** arrays[] = {(void**)&T->nodes, (void**)&T->node_head, (void**)&T->bmin, (void**)&T->bmax, (void**)&T->range, (void**)&T->quad};
     for (void** a : arrays) {
         if (*a) (void)hipFree(*a);
         *a = nullptr;
@@ -1268,7 +1051,6 @@ int ensure_nodes(nbody_ctx* ctx, Octree* T, uint64_t need) {
     T->have_tree = false;
     // the traversal fetches whole batches: pad so that the last group's batch stays inside
     hipError_t e = hipMalloc(&T->nodes, (cap + WALK_BATCH) * sizeof(QNode));
-    if (e == hipSuccess) e = hipMalloc(&T->pairs, 2 * pair_half(cap) * sizeof(QPair));
     if (e == hipSuccess) e = hipMalloc(&T->range, cap * sizeof(float));
     if (e == hipSuccess && ctx->cfg.quadrupole) e = hipMalloc(&T->quad, (cap + WALK_BATCH) * 8 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&T->node_head, cap * sizeof(uint32_t));
@@ -1300,14 +1082,6 @@ int check_err_flag(nbody_ctx* ctx, Octree* T, const char* what) {
     return NBODY_OK;
 }
 
-// The pair form of the records, with the padding a whole batch may read set to null records.
-void pairify(nbody_ctx* ctx, Octree* T) {
-    // (thread f fills pair f / 2 of array f & 1: through the padding a batch at the last record may read)
-    const uint32_t n_out = (uint32_t)(T->n_nodes + 2 * WALK_PBATCH + 2);
-    hipLaunchKernelGGL(k_pairify, dim3((n_out + 255) / 256), dim3(256), 0, ctx->stream, T->nodes, (uint32_t)T->n_nodes, n_out,
-                       (uint32_t)pair_half(T->cap_nodes), (QPair*)T->pairs);
-}
-
 template <int LAW>
 void launch_walk(nbody_ctx* ctx, Octree* T, const uint32_t* order, uint32_t m, const float4* posm, const float4* vel,
                  float4* acc_out, uint32_t i_begin, int out_by_rank) {
@@ -1318,24 +1092,6 @@ void launch_walk(nbody_ctx* ctx, Octree* T, const uint32_t* order, uint32_t m, c
     const bool ordered = grid.x <= 8 * ORDER_MAX && grid.x >= 64;
     const uint32_t* perm = ordered && T->perm_nblk == grid.x && T->perm_order == order ? T->wave_perm : nullptr;
     uint32_t* cost = ordered ? T->wave_cost : nullptr;
-    // The pair form costs a pass over the records (they are written in both alignments): taken when
-    // this traversal covers at least half the bodies, or the pairs of this tree exist already.  A
-    // rank of a many-GPU run, walking an eighth of the bodies of a replicated tree, keeps the
-    // one-record kernel.
-    static const bool no_pairs = getenv("NBODY_WALK_SINGLE") != nullptr;
-    if (LAW == NBODY_LAW_PLUMMER && !quad && !no_pairs && (T->pairs_valid || 2 * (uint64_t)m >= T->n)) {
-        if (!T->pairs_valid) {
-            pairify(ctx, T);
-            T->pairs_valid = true;
-        }
-#define NB_WALK_PAIR(COUNT)                                                                                               \
-    hipLaunchKernelGGL((k_walk_pair<COUNT>), grid, dim3(WALK_THREADS), 0, ctx->stream, (const QPair*)T->pairs, (uint32_t)pair_half(T->cap_nodes), order, m, i_begin, posm,  \
-                       acc_out, ctx->cfg.G, ctx->cfg.eps2, ctx->cfg.theta, T->range, (unsigned long long*)T->walk_counters, \
-                       T->err_flag, out_by_rank, perm, cost)
-        if (ctx->counting) { NB_WALK_PAIR(true); }
-        else { NB_WALK_PAIR(false); }
-#undef NB_WALK_PAIR
-    } else {
 #define NB_WALK(COUNT, QUAD)                                                                                              \
     hipLaunchKernelGGL((k_walk<LAW, COUNT, QUAD>), grid, dim3(WALK_THREADS), 0, ctx->stream, T->nodes, order, m, i_begin, posm, \
                        vel, acc_out, ctx->cfg.G, ctx->cfg.eps2, ctx->cfg.theta, T->range,                                 \
@@ -1348,7 +1104,6 @@ void launch_walk(nbody_ctx* ctx, Octree* T, const uint32_t* order, uint32_t m, c
         else { NB_WALK(false, false); }
     }
 #undef NB_WALK
-    }
     if (ordered) {
         // refreshed now and then: the visit counts drift slowly
         if (!perm || ++T->perm_age >= 8) {
@@ -1412,7 +1167,7 @@ void nb_tree_destroy(nbody_ctx* ctx) {
         if (T->idx[s]) hipFree(T->idx[s]);
     }
     void* ptrs[] = {T->lo, T->top, T->flags, T->body_node, T->rs_counts, T->row_total, T->blk,
-                    T->lvl_total, T->lvl_start, T->nodes, T->pairs, T->node_head, T->bmin, T->bmax, T->range, T->quad, T->export_buf, T->shard_order, T->shard_blk,
+                    T->lvl_total, T->lvl_start, T->nodes, T->node_head, T->bmin, T->bmax, T->range, T->quad, T->export_buf, T->shard_order, T->shard_blk,
                     T->walk_counters, T->err_flag, T->wave_cost, T->wave_perm};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -1501,7 +1256,6 @@ int nb_tree_build(nbody_ctx* ctx, const float4* posm_in) {
                                ctx->cfg.leaflist_mode);
         }
     }
-    T->pairs_valid = false;
     nb_time_end(ctx, 2);
     NB_HIP(ctx, hipGetLastError());
     T->have_tree = true;
@@ -1685,10 +1439,9 @@ int nb_tree_upload(nbody_ctx* ctx, const nbody_octree_node* host_nodes, uint64_t
     const uint32_t cnt = (uint32_t)kept;
     hipLaunchKernelGGL(k_import, dim3((cnt + 255) / 256), dim3(256), 0, ctx->stream, T->export_buf, cnt, T->nodes, T->bmin,
                        T->bmax, T->range, mac_scale(ctx), T->err_flag);
-    T->n_nodes = kept;
-    T->pairs_valid = false;
     NB_HIP(ctx, hipGetLastError());
     NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    T->n_nodes = kept;
     T->have_tree = true;
     T->built = false;  // no sorted order for this tree: targets are walked in index order
     T->export_is_upload = true;

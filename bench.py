@@ -312,7 +312,7 @@ def main():
                                   "bytes_per_launch": walk_bytes,
                                   "note": "algorithmic bytes = 32 B x wavefront node visits + 48 B per body, per GPU; the "
                                           "records are served by L2 / Infinity Cache and the kernel is bound by instruction "
-                                          "issue (17 VALU + 12 scalar instructions per wavefront visit), not by HBM"},
+                                          "issue (16 VALU + 12 scalar-unit instructions per wavefront visit, profiles/r02_pmc_walk_sq.json), not by HBM"},
                 "equivalent_allpairs_interactions_per_s": float(nbodies) * nbodies * bsteps / bdt}
 
     def extra(key, fn):

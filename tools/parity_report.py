@@ -64,6 +64,6 @@ allpairs("config2 all-pairs N=65536", 65536, ["wgsl_bias", "plummer"], "plummer"
 allpairs("config3 all-pairs N=1048576 (4 target ranges)", 1 << 20, ["wgsl_bias", "plummer"], "plummer")
 allpairs("all-pairs N=1048576+777 (padded last superblock)", (1 << 20) + 777, ["plummer"], "plummer")
 barnes_hut("config4 Barnes-Hut N=1048576", 1 << 20, ["wgsl_bias", "plummer"], 8192)
-barnes_hut("config5 Barnes-Hut N=16777216", 1 << 24, ["plummer"], 4096)
+barnes_hut("config5 Barnes-Hut N=16777216", 1 << 24, ["wgsl_bias", "plummer"], 4096)
 os.makedirs(os.path.dirname(out_path) or ".", exist_ok=True)
 json.dump(report, open(out_path, "w"), indent=1)

@@ -5,17 +5,24 @@
 // The window, camera and ray tracer of the reference are not reproduced: each "frame" is one
 // call of nbody_step_*; every `--report` frames the positions are read back, as the Barnes-Hut
 // binary does every frame (src/nbody_gpu_bh.rs:496-516).
+// --law cpu_r6|wgsl_bias|plummer overrides the mode's force law (--mode gpu --law plummer is the
+// softened Newtonian law, whose all-pairs step uses the pair kernel from N = 65,536).
+// --dataset refcube|plummer: the reference's initial conditions (src/nbody_gpu.rs:61-81, seeded) or
+// the Plummer sphere of the benchmarks.
 // --dump FILE writes what the reference's renderer binds (src/trace.wgsl:23-27): a 16-byte header
 // {"NBF1", u32 n, u32 frames written, u32 0}, masses f32[n], then per reported frame the positions
 // as f32[n][4] (vec3 stride 16, pad lane 0), so that a viewer can replay the run.
-// --ranks R runs R processes, one per GPU (device = rank mod device count), that exchange inside the
-// library over RCCL (nbody_comm_init): the all-pairs modes split the targets into R index ranges,
+// --ranks R runs R processes, one per GPU (device = rank mod --devices, default R), that exchange
+// inside the library (nbody_comm_init): the all-pairs modes split the targets into R index ranges,
 // the Barnes-Hut mode keeps all bodies on every rank and splits the traversal.  Rank 0 makes the
-// communicator's id and leaves it in a file for the others; rank 0 reports.
+// communicator's id and leaves it in a file for the others; rank 0 reports.  The process started
+// by the user only supervises: every rank is a child forked before anything touches the GPU, and
+// when one of them fails the others are ended and the id file removed.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <csignal>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -23,7 +30,18 @@
 #include <unistd.h>
 #include "../include/nbody_hip.h"
 
-static int die(nbody_ctx* ctx, const char* what, int rc) {
+namespace {
+
+struct Options {
+    int ranks = 1, devices = 0;
+    bool force_comm = false;
+    std::string mode = "gpu", law, dataset = "refcube", dump;
+    uint64_t n = 250;  // N_BODIES, src/nbody_gpu.rs:14
+    int frames = 100, report = 50;
+    uint64_t seed = 42;
+};
+
+int die(nbody_ctx* ctx, const char* what, int rc) {
     std::fprintf(stderr, "%s failed (%d): %s\n", what, rc, nbody_last_error(ctx));
     if (ctx) nbody_destroy(ctx);
     return 1;
@@ -31,7 +49,7 @@ static int die(nbody_ctx* ctx, const char* what, int rc) {
 
 // Rank 0 writes the 128-byte id to `path` (via a rename, so a reader never sees half of it); the
 // others wait for the file.
-static bool share_id(const std::string& path, int rank, unsigned char id[128]) {
+bool share_id(const std::string& path, int rank, unsigned char id[128]) {
     if (rank == 0) {
         if (nbody_comm_unique_id(id)) return false;
         const std::string tmp = path + ".tmp";
@@ -52,80 +70,52 @@ static bool share_id(const std::string& path, int rank, unsigned char id[128]) {
     return false;
 }
 
-int main(int argc, char** argv) {
-    int ranks = 1;
-    bool force_comm = false;
-    std::string mode = "gpu";
-    uint64_t n = 250;  // N_BODIES, src/nbody_gpu.rs:14
-    int frames = 100, report = 50;
-    uint64_t seed = 42;
-    std::string dump;
-    for (int i = 1; i < argc; ++i) {
-        std::string a = argv[i];
-        auto next = [&]() { return (i + 1 < argc) ? argv[++i] : (char*)"0"; };
-        if (a == "--mode") mode = next();
-        else if (a == "--n") n = std::strtoull(next(), nullptr, 10);
-        else if (a == "--frames") frames = std::atoi(next());
-        else if (a == "--report") report = std::atoi(next());
-        else if (a == "--seed") seed = std::strtoull(next(), nullptr, 10);
-        else if (a == "--dump") dump = next();
-        else if (a == "--ranks") ranks = std::atoi(next());
-        else if (a == "--comm") force_comm = true;  // a communicator even with one rank
-        else { std::fprintf(stderr, "usage: %s [--mode cpu|gpu|bh] [--n N] [--frames F] [--report R] [--seed S] [--dump FILE] [--ranks R] [--comm]\n", argv[0]); return 2; }
-    }
-    // one process per rank, forked before anything touches the GPU
-    int rank = 0;
-    std::vector<pid_t> children;
-    const std::string id_path = "/tmp/nbody_headless_id." + std::to_string((long)getpid());
-    if (ranks < 1 || (uint64_t)ranks > n) { std::fprintf(stderr, "--ranks must be in [1, n]\n"); return 2; }
-    for (int r = 1; r < ranks; ++r) {
-        pid_t pid = fork();
-        if (pid < 0) { std::perror("fork"); return 1; }
-        if (pid == 0) { rank = r; children.clear(); break; }
-        children.push_back(pid);
-    }
+// One rank's whole run (the only code that touches the library's GPU entry points).
+int run_rank(const Options& o, int rank, const std::string& id_path) {
+    const uint64_t n = o.n;
     nbody_config cfg;
     nbody_config_default(&cfg);
     cfg.n_bodies = n;
-    if (mode == "cpu") { cfg.law = NBODY_LAW_CPU_R6; cfg.integrator = NBODY_INT_CPU_EULER_XBUF; }
-    if (ranks > 1) {
-        cfg.device = rank;  // taken modulo the device count below
-        if (mode != "bh") {  // contiguous near-equal index ranges; Barnes-Hut keeps all bodies on every rank
-            const uint64_t base = n / ranks, extra = n % ranks;
+    if (o.mode == "cpu") { cfg.law = NBODY_LAW_CPU_R6; cfg.integrator = NBODY_INT_CPU_EULER_XBUF; }
+    if (o.law == "cpu_r6") cfg.law = NBODY_LAW_CPU_R6;
+    else if (o.law == "wgsl_bias") cfg.law = NBODY_LAW_WGSL_BIAS;
+    else if (o.law == "plummer") cfg.law = NBODY_LAW_PLUMMER;
+    if (o.ranks > 1) {
+        cfg.device = rank % o.devices;
+        if (o.mode != "bh") {  // contiguous near-equal index ranges; Barnes-Hut keeps all bodies on every rank
+            const uint64_t base = n / o.ranks, extra = n % o.ranks;
             cfg.shard_begin = rank * base + std::min<uint64_t>(rank, extra);
             cfg.shard_count = base + ((uint64_t)rank < extra ? 1 : 0);
         }
     }
     std::vector<float> masses(n), pos(4 * n);
-    nbody_gen_refcube(seed, 0, n, cfg.world, masses.data(), pos.data());  // src/nbody_gpu.rs:61-81
+    if (o.dataset == "plummer")  // the benchmarks' sphere: a = 12.5, cut at 8 a, the reference's expected total mass
+        nbody_gen_plummer(o.seed, 0, n, n, cfg.world, 12.5f, 100.0f, 4515.625f, cfg.G, 0, masses.data(), pos.data(), nullptr);
+    else
+        nbody_gen_refcube(o.seed, 0, n, cfg.world, masses.data(), pos.data());  // src/nbody_gpu.rs:61-81
     nbody_ctx* ctx = nullptr;
     int rc = nbody_create(&ctx, &cfg);
-    if (rc == NBODY_ERR_NO_DEVICE && ranks > 1 && cfg.device > 0) {  // fewer GPUs than ranks: share them
-        cfg.device = 0;
-        rc = nbody_create(&ctx, &cfg);
-    }
     if (rc) return die(nullptr, "nbody_create", rc);
-    if (ranks > 1 || force_comm) {
+    if (o.ranks > 1 || o.force_comm) {
         unsigned char id[128];
         if (!share_id(id_path, rank, id)) { std::fprintf(stderr, "rank %d: no communicator id\n", rank); nbody_destroy(ctx); return 1; }
-        if ((rc = nbody_comm_init(ctx, id, rank, ranks))) return die(ctx, "nbody_comm_init", rc);
+        if ((rc = nbody_comm_init(ctx, id, rank, o.ranks))) return die(ctx, "nbody_comm_init", rc);
     }
-    if (rank != 0) dump.clear();
     if ((rc = nbody_upload(ctx, masses.data(), pos.data(), nullptr, nullptr))) return die(ctx, "nbody_upload", rc);
     std::FILE* out = nullptr;
     uint32_t dumped = 0;
-    if (!dump.empty()) {
-        out = std::fopen(dump.c_str(), "wb");
-        if (!out) { std::fprintf(stderr, "cannot open %s\n", dump.c_str()); nbody_destroy(ctx); return 1; }
+    if (rank == 0 && !o.dump.empty()) {
+        out = std::fopen(o.dump.c_str(), "wb");
+        if (!out) { std::fprintf(stderr, "cannot open %s\n", o.dump.c_str()); nbody_destroy(ctx); return 1; }
         const uint32_t head[4] = {0x3146424eu /* "NBF1" */, (uint32_t)n, 0u, 0u};
         std::fwrite(head, sizeof head, 1, out);
         std::fwrite(masses.data(), sizeof(float), n, out);
     }
     auto t0 = std::chrono::steady_clock::now();
-    for (int f = 1; f <= frames; ++f) {
-        rc = (mode == "bh") ? nbody_step_bh(ctx, 1) : nbody_step_allpairs(ctx, 1);
+    for (int f = 1; f <= o.frames; ++f) {
+        rc = (o.mode == "bh") ? nbody_step_bh(ctx, 1) : nbody_step_allpairs(ctx, 1);
         if (rc) return die(ctx, "step", rc);
-        if (report > 0 && f % report == 0) {
+        if (o.report > 0 && f % o.report == 0) {
             if ((rc = nbody_download(ctx, pos.data(), nullptr, nullptr))) return die(ctx, "nbody_download", rc);
             if (rank == 0) std::printf("frame %d: body0 = (%.9g, %.9g, %.9g)\n", f, pos[0], pos[1], pos[2]);
             if (out) {
@@ -134,25 +124,109 @@ int main(int argc, char** argv) {
             }
         }
     }
-    nbody_sync(ctx);
+    if ((rc = nbody_sync(ctx))) return die(ctx, "nbody_sync", rc);
     double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     nbody_counters_t c;
     nbody_counters(ctx, &c);
     if (rank == 0)
-        std::printf("%s: n=%llu ranks=%d frames=%d  %.3f ms/frame  %.1f frames/s  octree nodes (last) %llu\n", mode.c_str(),
-                    (unsigned long long)n, ranks, frames, 1e3 * s / frames, frames / s, (unsigned long long)c.octree_nodes);
+        std::printf("%s: n=%llu ranks=%d frames=%d  %.3f ms/frame  %.1f frames/s  octree nodes (last) %llu  all-pairs path %llu\n",
+                    o.mode.c_str(), (unsigned long long)n, o.ranks, o.frames, 1e3 * s / o.frames, o.frames / s,
+                    (unsigned long long)c.octree_nodes, (unsigned long long)c.allpairs_path);
     if (out) {
         std::fseek(out, 8, SEEK_SET);
         std::fwrite(&dumped, sizeof dumped, 1, out);
         std::fclose(out);
     }
     nbody_destroy(ctx);
-    int status = 0;
-    for (pid_t pid : children) {
-        int st = 0;
-        waitpid(pid, &st, 0);
-        if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) status = 1;
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    Options o;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        auto next = [&]() { return (i + 1 < argc) ? argv[++i] : (char*)"0"; };
+        if (a == "--mode") o.mode = next();
+        else if (a == "--law") o.law = next();
+        else if (a == "--dataset") o.dataset = next();
+        else if (a == "--n") o.n = std::strtoull(next(), nullptr, 10);
+        else if (a == "--frames") o.frames = std::atoi(next());
+        else if (a == "--report") o.report = std::atoi(next());
+        else if (a == "--seed") o.seed = std::strtoull(next(), nullptr, 10);
+        else if (a == "--dump") o.dump = next();
+        else if (a == "--ranks") o.ranks = std::atoi(next());
+        else if (a == "--devices") o.devices = std::atoi(next());
+        else if (a == "--comm") o.force_comm = true;  // a communicator even with one rank
+        else {
+            std::fprintf(stderr,
+                         "usage: %s [--mode cpu|gpu|bh] [--law cpu_r6|wgsl_bias|plummer] [--dataset refcube|plummer] [--n N] "
+                         "[--frames F] [--report R] [--seed S] [--dump FILE] [--ranks R] [--devices D] [--comm]\n",
+                         argv[0]);
+            return 2;
+        }
     }
-    if (rank == 0 && (ranks > 1 || force_comm)) std::remove(id_path.c_str());
+    if (o.mode != "cpu" && o.mode != "gpu" && o.mode != "bh") { std::fprintf(stderr, "--mode must be cpu, gpu or bh\n"); return 2; }
+    if (!o.law.empty() && o.law != "cpu_r6" && o.law != "wgsl_bias" && o.law != "plummer") {
+        std::fprintf(stderr, "--law must be cpu_r6, wgsl_bias or plummer\n");
+        return 2;
+    }
+    if (o.dataset != "refcube" && o.dataset != "plummer") { std::fprintf(stderr, "--dataset must be refcube or plummer\n"); return 2; }
+    if (o.ranks < 1 || (uint64_t)o.ranks > o.n) { std::fprintf(stderr, "--ranks must be in [1, n]\n"); return 2; }
+    if (o.frames < 1) { std::fprintf(stderr, "--frames must be at least 1\n"); return 2; }
+    if (o.devices <= 0) o.devices = o.ranks;
+    const char* transport = std::getenv("NBODY_RCCL_LIB");
+    if (o.devices < o.ranks && !(transport && *transport)) {
+        // RCCL refuses two ranks on one device: such a run could only fail or hang in nbody_comm_init
+        std::fprintf(stderr, "--devices %d < --ranks %d: RCCL needs one GPU per rank\n", o.devices, o.ranks);
+        return 2;
+    }
+    const std::string id_path = "/tmp/nbody_headless_id." + std::to_string((long)getpid());
+    if (o.ranks == 1) {
+        const int rc = run_rank(o, 0, id_path);
+        if (o.force_comm) std::remove(id_path.c_str());
+        return rc;
+    }
+    // one process per rank, forked before anything touches the GPU; this process only supervises
+    std::vector<pid_t> children;
+    for (int r = 0; r < o.ranks; ++r) {
+        std::fflush(nullptr);
+        pid_t pid = fork();
+        if (pid < 0) {
+            std::perror("fork");
+            for (pid_t c : children) kill(c, SIGKILL);
+            for (pid_t c : children) waitpid(c, nullptr, 0);
+            return 1;
+        }
+        if (pid == 0) {
+            const int rc = run_rank(o, r, id_path);
+            std::fflush(nullptr);
+            _exit(rc);
+        }
+        children.push_back(pid);
+    }
+    int status = 0;
+    size_t left = children.size();
+    while (left > 0) {
+        int st = 0;
+        const pid_t done = wait(&st);
+        if (done < 0) break;
+        auto it = std::find(children.begin(), children.end(), done);
+        if (it == children.end()) continue;
+        *it = -1;
+        --left;
+        if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) {
+            if (status == 0) {
+                // a rank that failed leaves the others waiting in a collective (or for the id): end them
+                std::fprintf(stderr, "a rank failed: ending the other %zu\n", left);
+                for (pid_t c : children)
+                    if (c > 0) kill(c, SIGKILL);
+            }
+            status = 1;
+        }
+    }
+    std::remove(id_path.c_str());
+    std::remove((id_path + ".tmp").c_str());
     return status;
 }

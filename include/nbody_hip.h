@@ -206,6 +206,26 @@ int nbody_integrate_ranked(nbody_ctx* ctx);
  * nbody_destroy releases the communicator. */
 int nbody_comm_unique_id(void* id_out128);
 int nbody_comm_init(nbody_ctx* ctx, const void* unique_id128, int rank, int world);
+/* The environment variable NBODY_RCCL_LIB, when set, names the library nbody_comm_unique_id and
+ * nbody_comm_init load in RCCL's place (it must export ncclGetUniqueId, ncclCommInitRank,
+ * ncclCommDestroy, ncclAllGather, ncclAllReduce, ncclBroadcast, ncclGroupStart, ncclGroupEnd and
+ * ncclGetErrorString).
+ * With a communicator, a failure on ONE rank between two collectives of a step (out of memory,
+ * a HIP error) leaves the other ranks waiting in the next collective: it ends the run.  The one
+ * decision that depends on a rank's own free memory -- whether the pair kernel's scratch fits -- is
+ * therefore taken by all ranks together (an all-reduce on the first nbody_step_allpairs).
+ *
+ * Plain arithmetic behind the exchange, callable without a device or a context (hosts that run the
+ * exchange themselves, and tests).  nbody_comm_sorted_run: the run [*begin, *begin + *count) of the
+ * sorted order whose targets `rank` of `world` traverses in nbody_step_bh: boundaries at
+ * n_bodies k / world rounded down to a multiple of 64, the last run ends at n_bodies; runs are
+ * empty where n_bodies < 64 world.  nbody_comm_exchange_plan: how ranges begin[k], count[k] (k <
+ * world) are exchanged: returns 1 = they tile [0, n_bodies) in rank order with equal counts (one
+ * in-place all-gather: begin[k] == k count[0]), 2 = they tile it with unequal or empty counts (one
+ * broadcast per non-empty rank), 3 = every rank holds all bodies (nothing to exchange), or
+ * NBODY_ERR_INVALID (gaps, overlaps, out of order), which nbody_comm_init refuses. */
+int nbody_comm_sorted_run(uint64_t n_bodies, int world, int rank, uint64_t* begin, uint64_t* count);
+int nbody_comm_exchange_plan(uint64_t n_bodies, int world, const uint64_t* begin, const uint64_t* count);
 
 /* Forces only (no integration, no swap), for parity checks against src/nbody.wgsl:50-116 and
  * src/nbodybh.wgsl:63-161.  host_acc16_out is f32[N][4]; only this context's targets are written. */
@@ -218,9 +238,15 @@ int nbody_accel_allpairs(nbody_ctx* ctx, float* host_acc16_out);
  * dev_acc16_out, f32[n][4] device memory, receives G * sum (pad lane 0).  Enqueued on `stream`
  * (a hipStream_t, NULL = the null stream); does not block.  The per-slice partial sums live in a
  * fixed 16 MiB device array inside the library (one per GPU, held until the process ends), which
- * limits n_bodies to 131,072: larger inputs return NBODY_ERR_CAPACITY.  Calls that overlap on one
- * GPU (two streams, two threads) share that array and race; calls on one stream are ordered.
- * nbody_last_error(NULL) has the message of a failure. */
+ * limits n_bodies to 131,072: larger inputs return NBODY_ERR_CAPACITY.  The array also caps the
+ * number of source slices (16 MiB / (16 B n_bodies)), and the pair kernel is never used here, so
+ * above N = 16,384 (and for the PLUMMER law from N = 65,536) the sums are split differently from
+ * nbody_accel_allpairs': the two agree to rounding (2e-6 relative), bit for bit only where both
+ * use the same slicing.  Calls that overlap on one GPU (two streams, two threads) share that array
+ * and race; calls on one stream are ordered.  The FIRST call on a device looks up the array's
+ * address and the device's size (hipGetSymbolAddress, hipDeviceGetAttribute): make it outside a
+ * graph capture.  nbody_last_error(NULL) has the message of the last failure of a call made
+ * without a context; a successful call clears it. */
 int nbody_accel_allpairs_noalloc(const float* dev_posm, const float* dev_vel16, uint64_t n_bodies, int law, float G,
                                  float eps2, float* dev_acc16_out, void* stream);
 /* Uses the tree currently held by the context (built or uploaded). */

@@ -66,6 +66,8 @@ SYMBOLS = {
     "nbody_integrate_ranked": (C.c_int, [_P]),
     "nbody_comm_unique_id": (C.c_int, [_P]),
     "nbody_comm_init": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "nbody_comm_sorted_run": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "nbody_comm_exchange_plan": (C.c_int, [C.c_uint64, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "nbody_accel_allpairs": (C.c_int, [_P, _P]),
     "nbody_accel_allpairs_noalloc": (C.c_int, [_P, _P, C.c_uint64, C.c_int, C.c_float, C.c_float, _P, _P]),
     "nbody_accel_bh": (C.c_int, [_P, _P]),

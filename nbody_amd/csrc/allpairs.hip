@@ -599,6 +599,12 @@ static bool sym_scratch_fits(nbody_ctx* ctx, uint32_t seg, int tpl, uint64_t* ne
     return hipMemGetInfo(&free_b, &total_b) == hipSuccess && need < free_b / 2;
 }
 
+// Whether this GPU can hold the pair kernel's partial rows (a communicator asks every rank).
+bool nb_allpairs_pair_fits(nbody_ctx* ctx) {
+    const int tpl = sym_tpl();
+    return sym_scratch_fits(ctx, sym_seg_tiles(ctx, tpl), tpl, nullptr);
+}
+
 // One part's share of the pair tiles of ALL bodies (PLUMMER): acc_tmp[j] for every j.
 int nb_allpairs_partial(nbody_ctx* ctx, uint32_t part, uint32_t nparts) {
     const int tpl = sym_tpl();
@@ -731,6 +737,7 @@ void nb_noalloc_clear_error() { g_noalloc_error = ""; }
 
 extern "C" int nbody_accel_allpairs_noalloc(const float* dev_posm, const float* dev_vel16, uint64_t n_bodies, int law, float G,
                                             float eps2, float* dev_acc16_out, void* stream) {
+    g_noalloc_error = "";  // the message belongs to the last call made without a context
     if (!dev_posm || !dev_acc16_out) return noalloc_fail(NBODY_ERR_INVALID, "nbody_accel_allpairs_noalloc: null buffer");
     if (law < 0 || law > 2) return noalloc_fail(NBODY_ERR_INVALID, "nbody_accel_allpairs_noalloc: unknown law");
     if (law == NBODY_LAW_WGSL_BIAS && !dev_vel16)
@@ -758,6 +765,7 @@ extern "C" int nbody_accel_allpairs_noalloc(const float* dev_posm, const float* 
                      part, (int)n_bodies, 0, (int)n_bodies, eps2};
     // every slice of every target is written by the force kernel before the sum reads it: nothing
     // of the previous call's contents is read, so the array needs no clearing
+    (void)hipGetLastError();  // an error left behind by an earlier, unrelated call is not this call's
     ap_forces_plain(a, law, pl);
     if (hipGetLastError() != hipSuccess) return noalloc_fail(NBODY_ERR_HIP, "nbody_accel_allpairs_noalloc: force kernel launch failed");
     ap_finalize(a, law, pl, G, reinterpret_cast<float4*>(dev_acc16_out));

@@ -319,8 +319,16 @@ int nbody_step_allpairs(nbody_ctx* ctx, int nsteps) {
         int rc = set_device(ctx);
         if (rc) return rc;
         ctx->pending_forces = 0;
+        // The pair kernel dealt over the ranks only if EVERY rank has room for its scratch: a rank
+        // that took the other path alone would leave the rest waiting in the all-reduce.  (Any
+        // other per-rank failure between two collectives does exactly that: it ends the run.)
+        bool pair = false;
+        if (ctx->comm && pair_sharded(ctx) && nsteps > 0) {
+            rc = nb_comm_pair_path(ctx, nb_allpairs_pair_fits(ctx), &pair);
+            if (rc) return rc;
+        }
         for (int s = 0; s < nsteps; ++s) {
-            if (ctx->comm && pair_sharded(ctx)) {
+            if (pair) {
                 rc = nb_allpairs_partial(ctx, (uint32_t)nb_comm_rank(ctx), (uint32_t)nb_comm_world(ctx));
                 if (rc) return rc;
                 rc = nb_comm_allreduce_partial(ctx);
@@ -579,14 +587,18 @@ int nbody_counters(nbody_ctx* ctx, nbody_counters_t* out) {
 
 int nbody_counters_reset(nbody_ctx* ctx) {
     if (!ctx) return NBODY_ERR_INVALID;
-    ctx->counters = nbody_counters_t{};
-    return NBODY_OK;
+    return guarded(ctx, [&]() -> int {
+        ctx->counters = nbody_counters_t{};
+        return NBODY_OK;
+    });
 }
 
 int nbody_set_counting(nbody_ctx* ctx, int on) {
     if (!ctx) return NBODY_ERR_INVALID;
-    ctx->counting = on != 0;
-    return NBODY_OK;
+    return guarded(ctx, [&]() -> int {
+        ctx->counting = on != 0;
+        return NBODY_OK;
+    });
 }
 
 int nbody_device_buffer(nbody_ctx* ctx, int which, void** dev_ptr, size_t* bytes) {
@@ -679,6 +691,7 @@ int nbody_kernel_time(nbody_ctx* ctx, int which, double* avg_ms, uint64_t* launc
 
 int nbody_comm_unique_id(void* id_out128) {
     if (!id_out128) return NBODY_ERR_INVALID;
+    nb_noalloc_clear_error();  // nbody_last_error(NULL) reports the last call made without a context
     try {
         int r = nb_comm_unique_id(id_out128);
         if (r) g_nbody_create_error = "nbody_comm_unique_id: librccl could not be loaded or ncclGetUniqueId failed";
@@ -686,6 +699,18 @@ int nbody_comm_unique_id(void* id_out128) {
     } catch (...) {
         return NBODY_ERR_NOMEM;
     }
+}
+
+int nbody_comm_sorted_run(uint64_t n_bodies, int world, int rank, uint64_t* begin, uint64_t* count) {
+    if (!begin || !count || world < 1 || rank < 0 || rank >= world) return NBODY_ERR_INVALID;
+    nb_sorted_run(n_bodies, (uint64_t)world, (uint64_t)rank, begin, count);
+    return NBODY_OK;
+}
+
+int nbody_comm_exchange_plan(uint64_t n_bodies, int world, const uint64_t* begin, const uint64_t* count) {
+    if (!begin || !count || world < 1) return NBODY_ERR_INVALID;
+    const int plan = nb_exchange_plan(n_bodies, world, begin, count);
+    return plan == NB_PLAN_INVALID ? NBODY_ERR_INVALID : plan;
 }
 
 int nbody_comm_init(nbody_ctx* ctx, const void* unique_id128, int rank, int world) {

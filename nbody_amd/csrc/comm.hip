@@ -14,6 +14,7 @@
 // on it; a process that already holds an RCCL (PyTorch ships one) shares that copy.
 #include "ctx.h"
 #include <dlfcn.h>
+#include <cstdlib>
 #include <cstring>
 #include <rccl/rccl.h>
 #include <vector>
@@ -24,6 +25,7 @@ struct NbComm {
     int rank = 0, world = 1;
     std::vector<uint64_t> begin, count;  // every rank's target range (all-pairs)
     bool equal_counts = true;
+    int pair_path = -1;  // all-pairs, PLUMMER: 1 every rank can run the pair kernel, 0 some rank cannot, -1 not asked yet
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
@@ -37,6 +39,11 @@ struct NbComm {
 namespace {
 
 void* open_rccl() {
+    // NBODY_RCCL_LIB names another library with RCCL's entry points (a test transport, a newer
+    // RCCL); nothing else is tried then
+    if (const char* over = std::getenv("NBODY_RCCL_LIB")) {
+        if (*over) return dlopen(over, RTLD_NOW | RTLD_LOCAL);
+    }
     // a copy already in the process first (same SONAME: the loader would hand it out anyway)
     for (const char* name : {"librccl.so.1", "librccl.so"}) {
         if (void* h = dlopen(name, RTLD_NOW | RTLD_NOLOAD)) return h;
@@ -61,6 +68,34 @@ bool bind(void* dl, const char* name, F& fn) {
 }
 
 }  // namespace
+
+// ---- who holds what: plain arithmetic, no device --------------------------------------------
+// Rank k's run of the sorted order: [b(k), b(k + 1)) with b(k) = n k / world rounded down to a
+// multiple of 64 (whole wavefronts of targets), b(world) = n.  Runs may be empty (n < 64 world).
+void nb_sorted_run(uint64_t n, uint64_t world, uint64_t k, uint64_t* begin, uint64_t* count) {
+    auto bound = [&](uint64_t r) { return r >= world ? n : (n * r / world) / 64 * 64; };
+    *begin = bound(k);
+    *count = bound(k + 1) - *begin;
+}
+
+// How the ranks' ranges [begin[k], begin[k] + count[k]) are exchanged.  NB_PLAN_ALLGATHER: they tile
+// [0, n) in rank order with equal counts, so begin[k] == k * count[0] and ONE in-place all-gather
+// does it; NB_PLAN_BROADCASTS: they tile [0, n) with unequal (possibly empty) counts, one broadcast
+// per non-empty rank; NB_PLAN_REPLICATED: every rank holds all bodies, nothing to exchange;
+// NB_PLAN_INVALID: anything else (gaps, overlaps, out of rank order).
+int nb_exchange_plan(uint64_t n, int world, const uint64_t* begin, const uint64_t* count) {
+    bool tiles = true, whole = true, equal = true;
+    uint64_t next = 0;
+    for (int k = 0; k < world; ++k) {
+        tiles = tiles && begin[k] == next && count[k] <= n - next;
+        if (tiles) next = begin[k] + count[k];
+        whole = whole && begin[k] == 0 && count[k] == n;
+        equal = equal && count[k] == count[0];
+    }
+    tiles = tiles && next == n;
+    if (tiles) return equal ? NB_PLAN_ALLGATHER : NB_PLAN_BROADCASTS;
+    return whole ? NB_PLAN_REPLICATED : NB_PLAN_INVALID;
+}
 
 int nb_comm_unique_id(void* id128) {
     void* dl = open_rccl();
@@ -128,21 +163,50 @@ int nb_comm_init(nbody_ctx* ctx, const void* id128, int rank, int world) {
     if (e != hipSuccess) return fail(NBODY_ERR_HIP, std::string("nbody_comm_init: ") + hipGetErrorString(e));
     C->begin.resize(world);
     C->count.resize(world);
-    bool tiles = true, whole = true;
-    uint64_t next = 0;
     for (int k = 0; k < world; ++k) {
         C->begin[k] = all[2 * k];
         C->count[k] = all[2 * k + 1];
-        tiles = tiles && C->begin[k] == next;
-        next = C->begin[k] + C->count[k];
-        whole = whole && C->begin[k] == 0 && C->count[k] == ctx->n;
-        C->equal_counts = C->equal_counts && C->count[k] == C->count[0];
     }
-    tiles = tiles && next == ctx->n;
     // either the ranks' target ranges tile [0, N) in rank order (all-pairs), or every rank holds
     // all bodies (Barnes-Hut with replicated state; also all-pairs on one rank)
-    if (!tiles && !whole)
+    const int plan = nb_exchange_plan(ctx->n, world, C->begin.data(), C->count.data());
+    if (plan == NB_PLAN_INVALID)
         return fail(NBODY_ERR_INVALID, "nbody_comm_init: the ranks' shard ranges must tile [0, n_bodies) in rank order, or every rank must hold all bodies");
+    C->equal_counts = plan != NB_PLAN_BROADCASTS;
+    return NBODY_OK;
+}
+
+// Whether EVERY rank can run the pair kernel (its scratch depends on the free memory of each GPU):
+// asked once, the answer kept.  A rank that took the other path alone would leave the rest waiting
+// in the all-reduce.
+int nb_comm_all_agree(nbody_ctx* ctx, int mine, int* all) {
+    NbComm* C = ctx->comm;
+    int* dev = nullptr;
+    if (hipMalloc(&dev, sizeof(int)) != hipSuccess) {
+        (void)hipGetLastError();
+        return nb_fail(ctx, NBODY_ERR_NOMEM, "nbody_step_allpairs: out of device memory");
+    }
+    int got = 0;
+    hipError_t e = hipMemcpyAsync(dev, &mine, sizeof mine, hipMemcpyHostToDevice, ctx->stream);
+    ncclResult_t r = ncclSuccess;
+    if (e == hipSuccess) r = C->AllReduce(dev, dev, 1, ncclInt32, ncclMin, C->comm, ctx->stream);
+    if (e == hipSuccess && r == ncclSuccess) e = hipMemcpyAsync(&got, dev, sizeof got, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && r == ncclSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(dev);
+    if (r != ncclSuccess) return nb_fail(ctx, NBODY_ERR_HIP, std::string("ncclAllReduce: ") + C->GetErrorString(r));
+    if (e != hipSuccess) return nb_fail(ctx, NBODY_ERR_HIP, std::string("nbody_step_allpairs: ") + hipGetErrorString(e));
+    *all = got;
+    return NBODY_OK;
+}
+
+int nb_comm_pair_path(nbody_ctx* ctx, bool fits_here, bool* use_pair) {
+    NbComm* C = ctx->comm;
+    if (C->pair_path < 0) {
+        int all = 0;
+        if (int rc = nb_comm_all_agree(ctx, fits_here ? 1 : 0, &all)) return rc;
+        C->pair_path = all ? 1 : 0;
+    }
+    *use_pair = C->pair_path == 1;
     return NBODY_OK;
 }
 
@@ -179,23 +243,15 @@ int nb_comm_allreduce_partial(nbody_ctx* ctx) {
     return NBODY_OK;
 }
 
-// Rank k's run of the sorted order: [b(k), b(k + 1)) with b(k) = n k / world rounded down to a
-// multiple of 64 (whole wavefronts of targets), b(world) = n.
 void nb_comm_run(const nbody_ctx* ctx, int k, uint64_t* begin, uint64_t* count) {
-    const uint64_t w = (uint64_t)ctx->comm->world;
-    auto bound = [&](uint64_t r) { return r >= w ? ctx->n : (ctx->n * r / w) / 64 * 64; };
-    *begin = bound((uint64_t)k);
-    *count = bound((uint64_t)k + 1) - *begin;
+    nb_sorted_run(ctx->n, (uint64_t)ctx->comm->world, (uint64_t)k, begin, count);
 }
 
 int nb_comm_gather_ranked(nbody_ctx* ctx) {
     NbComm* C = ctx->comm;
     std::vector<uint64_t> begin(C->world), count(C->world);
-    bool equal = true;
-    for (int k = 0; k < C->world; ++k) {
-        nb_comm_run(ctx, k, &begin[k], &count[k]);
-        equal = equal && count[k] == count[0];
-    }
+    for (int k = 0; k < C->world; ++k) nb_comm_run(ctx, k, &begin[k], &count[k]);
+    const bool equal = nb_exchange_plan(ctx->n, C->world, begin.data(), count.data()) == NB_PLAN_ALLGATHER;
     return exchange_rows(ctx, ctx->acc_tmp, begin, count, equal);
 }
 

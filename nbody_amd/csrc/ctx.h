@@ -108,6 +108,11 @@ int nb_comm_gather_positions(nbody_ctx* ctx);   // every rank's own targets of p
 int nb_comm_allreduce_partial(nbody_ctx* ctx);  // acc_tmp summed over the ranks
 int nb_comm_gather_ranked(nbody_ctx* ctx);      // acc_tmp by sorted rank: every rank's run to every rank
 void nb_comm_run(const nbody_ctx* ctx, int k, uint64_t* begin, uint64_t* count);
+void nb_sorted_run(uint64_t n, uint64_t world, uint64_t k, uint64_t* begin, uint64_t* count);
+enum { NB_PLAN_INVALID = 0, NB_PLAN_ALLGATHER = 1, NB_PLAN_BROADCASTS = 2, NB_PLAN_REPLICATED = 3 };
+int nb_exchange_plan(uint64_t n, int world, const uint64_t* begin, const uint64_t* count);
+int nb_comm_pair_path(nbody_ctx* ctx, bool fits_here, bool* use_pair);  // collective: asked once, then remembered
+bool nb_allpairs_pair_fits(nbody_ctx* ctx);
 int nb_comm_rank(const nbody_ctx* ctx);
 int nb_comm_world(const nbody_ctx* ctx);
 

@@ -932,6 +932,10 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(7,
                 // The lanes among them that open it: clearly to be opened, or inside the band between
                 // the thresholds, where the reference's own expression decides.
                 auto opening = [&]() {
+                    // A LEAFBODY record is never opened (src/nbodybh.wgsl:76-102 interacts with it whatever
+                    // the distance); lanes reach this point for one only when r2 is NaN, and then take the
+                    // term, NaN and all, as the reference does.
+                    if (qn_type(nd) == NBODY_NODE_LEAFBODY) return 0ull;
                     unsigned long long open = rest;
                     const unsigned long long unsure = rest & lanes(!(r2 < nd.r2_open));
                     if (unsure) {
@@ -939,7 +943,7 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(7,
                         const float rr = sqrtf(((dx * dx) + (dy * dy)) + (dz * dz));  // distance(pos, com)
                         open &= ~(unsure & lanes((rg / rr) < theta));
                     }
-                    if (open) {
+                    if (open && qn_count(nd)) {  // (an empty group is never pushed: a popped group has >= 1 record)
                         // INTERIOR: its children; LEAFLIST: its members (LEAFBODY records, src/nbodybh.wgsl:137-146)
                         if (top_v < WALK_STACK) {
                             stack[top_v] = make_uint4(nd.first, qn_count(nd), (uint32_t)open, (uint32_t)(open >> 32));
@@ -1394,6 +1398,7 @@ int nb_tree_upload(nbody_ctx* ctx, const nbody_octree_node* host_nodes, uint64_t
         const nbody_octree_node& nd = host_nodes[bfs[head]];
         if (nd.node_type > NBODY_NODE_INTERIOR) return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_upload_octree: bad node_type");
         if (nd.node_type == NBODY_NODE_INTERIOR) {
+            size_t children = 0;
             for (int k = 0; k < 8; ++k) {
                 const uint32_t c = nd.child_indices[k];
                 if (c == 0) continue;
@@ -1401,7 +1406,10 @@ int nb_tree_upload(nbody_ctx* ctx, const nbody_octree_node* host_nodes, uint64_t
                 if (new_id[c] != NO_NODE) return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_upload_octree: a node has two parents");
                 new_id[c] = (uint32_t)bfs.size();
                 bfs.push_back(c);
+                ++children;
             }
+            // (the builders never make one: src/octree_maxdepth.rs:139-184 gives an interior node the new body's child)
+            if (!children) return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_upload_octree: an INTERIOR node has no children");
         } else if (nd.node_type == NBODY_NODE_LEAFLIST) {
             const uint64_t first = nd.child_indices[0], cnt = std::max<uint32_t>(nd.child_indices[1], 1u);
             if (first + cnt > n_nodes) return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_upload_octree: leaf list outside the node array");

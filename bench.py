@@ -26,6 +26,35 @@ FLOP_PER_CLOCK = 256 * 256  # whole chip, FP32 vector
 # 2 mul for r^-3, 3 fma on the targets, 3 mul/fma for the reaction = 24 flop (26 with unequal masses)
 EXECUTED_FLOP_PER_PAIR = 24
 PEAK_HBM_GBPS = 8000.0
+N_SIMDS = 256 * 4
+NOMINAL_CLOCK_MHZ = 2400.0
+# SIMD cycles one wavefront node visit of the traversal costs when nothing but its own instruction
+# sequence is in the way: that sequence run alone, records as constant scalar operands, 6-8 resident
+# wavefronts per SIMD (tools/ubench_walkmix.hip, sequence A; profiles/r02_ubench_walkmix.txt: 56-61)
+WALK_ISSUE_CYCLES_PER_VISIT = {"plummer": 56.0}
+
+
+def profile_traffic(pattern, pick):
+    """HBM bytes per launch measured offline with rocprofv3 --pmc (FETCH_SIZE and WRITE_SIZE in
+    separate passes, summaries under profiles/): PMC counters cannot be read from inside this
+    process.  The newest summary that has the entry wins.  Returns (bytes, file) or (None, None)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
+        try:
+            v = pick(json.load(open(path)))
+        except (OSError, KeyError, ValueError, TypeError, IndexError):
+            v = None
+        if v is not None:
+            return float(v), "profiles/" + os.path.basename(path)
+    return None, None
+
+
+def kernel_entry(kernels, name):
+    """The entry of a kernel in a per-kernel summary, whatever its template arguments."""
+    for k, v in kernels.items():
+        if k == name or k.startswith(name + "<"):
+            return v
+    raise KeyError(name)
 
 
 def cpu_baseline(seconds_budget=10.0):
@@ -208,13 +237,16 @@ def main():
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process;
     # the value measured with rocprofv3 (separate FETCH_SIZE / WRITE_SIZE passes over this same
     # command) is kept under profiles/ and quoted when it is for this workload.
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_allpairs.json")))
-        if (pmc["n_bodies"], pmc["n_gpus"], pmc["law"]) == (n, args.gpus, args.law) and out["roofline"]["kernel"] in pmc["kernels"]:
-            out["roofline"]["traffic"] = pmc["kernels"][out["roofline"]["kernel"]]["hbm_bytes_per_launch"]
-            out["roofline"]["traffic_source"] = "profiles/r02_pmc_allpairs.json (rocprofv3 --pmc over this command, offline)"
-    except (OSError, KeyError, ValueError):
-        pass
+    def ap_pick(pmc):
+        if (pmc["n_bodies"], pmc["law"]) != (n, args.law):
+            return None
+        b = kernel_entry(pmc["kernels"], rf["kernel"])["hbm_bytes_per_launch"]
+        return b / world if pmc["n_gpus"] == 1 else None   # a rank's launch covers 1 / world of the pair work
+
+    rf["traffic"], src = profile_traffic("r*_pmc_allpairs.json", ap_pick)
+    if src:
+        rf["traffic_source"] = src + " (rocprofv3 --pmc over `bench.py --no-extras`, offline, one GPU" + \
+            ("; divided by the rank count)" if world > 1 else ")")
     if not args.no_extras and args.law == "plummer":
         # the reference's shader law (src/nbody.wgsl:54-81) on the same bodies, fewer steps
         wsteps = max(1, min(2, args.steps))
@@ -288,31 +320,50 @@ def main():
             dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         inter, visits, wave_visits = (float(x) for x in tot)
         bdt, wms, bms = float(mx[0]), float(mx[1]), float(mx[2])
-        # bytes the traversal asks for: 32 B per wavefront node visit + per-body reads/writes
-        walk_bytes = (32.0 * wave_visits + nbodies * (16 + 16 + 16)) / world
+        # bytes the traversal asks for: 32 B per wavefront node visit + per body 3 x 16 B read, 48 B written
+        walk_bytes = (32.0 * wave_visits + nbodies * (16 + 16 + 16 + 48)) / world
         # algorithmic bytes of one (replicated) build: bodies read, keys + indices written, six
         # sort passes of 12 B in and out, bodies read again for the nodes, 32 B records written and
         # read once more by the aggregate passes
         build_bytes = nbodies * (16.0 + 12 + 144 + 16) + c["octree_nodes"] * 64.0
-        return {"n_bodies": nbodies, "n_gpus": world, "law": "plummer" if bh_law in (None, nb.LAW_PLUMMER) else "wgsl_bias",
+        law_name = "plummer" if bh_law in (None, nb.LAW_PLUMMER) else "wgsl_bias"
+        pkey = f"n_{nbodies}" + ("" if law_name == "plummer" else "_wgsl_bias")
+        walk_traffic, walk_src = profile_traffic(
+            "r*_pmc_bh.json", lambda d: kernel_entry(d[pkey], "k_walk")["hbm_bytes_per_launch"] / world)
+        build_traffic, build_src = profile_traffic("r*_pmc_bh.json", lambda d: d[pkey]["octree_build_bytes_per_build"])
+        visits_per_s = wave_visits / world / (wms * 1e-3) if wms > 0 else 0.0
+        issue = None
+        if law_name in WALK_ISSUE_CYCLES_PER_VISIT:
+            cyc = WALK_ISSUE_CYCLES_PER_VISIT[law_name]
+            peak_visits = N_SIMDS * NOMINAL_CLOCK_MHZ * 1e6 / cyc
+            issue = {"bound": "issue", "achieved": visits_per_s, "peak": peak_visits, "unit": "wavefront node visits/s",
+                     "frac": visits_per_s / peak_visits, "cycles_per_visit_alone": cyc,
+                     "simd_cycles_per_visit": N_SIMDS * NOMINAL_CLOCK_MHZ * 1e6 / visits_per_s if visits_per_s > 0 else None,
+                     "clock_mhz": NOMINAL_CLOCK_MHZ, "simds": N_SIMDS,
+                     "note": "the ceiling the traversal actually has: wavefront node visits x the SIMD cycles one visit's "
+                             "instruction sequence takes alone (no memory, 6-8 wavefronts per SIMD: "
+                             "profiles/r02_ubench_walkmix.txt, sequence A) / (1,024 SIMDs x the nominal clock)"}
+        return {"n_bodies": nbodies, "n_gpus": world, "law": law_name,
                 "ranks_hold_identical_positions": same, "theta": 0.5, "max_depth": 16, "steps": bsteps,
                 "steps_per_s": bsteps / bdt, "ms_per_step": bdt / bsteps * 1e3, "walk_kernel_ms": wms,
                 "build_ms": bms,
                 "build_roofline": {"bound": "hbm", "achieved": build_bytes / (bms * 1e-3) / 1e9 if bms > 0 else None,
                                    "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                    "frac": build_bytes / (bms * 1e-3) / 1e9 / PEAK_HBM_GBPS if bms > 0 else None,
-                                   "bytes_per_build": build_bytes},
+                                   "bytes_per_build": build_bytes, "traffic": build_traffic, "traffic_source": build_src},
                 "octree_nodes": c["octree_nodes"], "interactions_per_step": inter,
                 "interactions_per_s": inter * bsteps / bdt, "node_visits_per_body": visits / nbodies,
                 "wave_node_visits": wave_visits,
+                "lane_utilisation": visits / (64.0 * wave_visits) if wave_visits > 0 else None,
                 "walk_roofline": {"bound": "hbm", "achieved": walk_bytes / (wms * 1e-3) / 1e9 if wms > 0 else None,
                                   "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                   "frac": walk_bytes / (wms * 1e-3) / 1e9 / PEAK_HBM_GBPS if wms > 0 else None,
-                                  "traffic": None, "kernel": "k_walk", "kernel_ms": wms,
+                                  "traffic": walk_traffic, "traffic_source": walk_src, "kernel": "k_walk", "kernel_ms": wms,
                                   "bytes_per_launch": walk_bytes,
-                                  "note": "algorithmic bytes = 32 B x wavefront node visits + 48 B per body, per GPU; the "
-                                          "records are served by L2 / Infinity Cache and the kernel is bound by instruction "
-                                          "issue (16 VALU + 12 scalar-unit instructions per wavefront visit, profiles/r02_pmc_walk_sq.json), not by HBM"},
+                                  "note": "algorithmic bytes = 32 B x wavefront node visits + 96 B per body, per GPU.  The "
+                                          "records are served by L2 / Infinity Cache; what limits the kernel is the issue "
+                                          "rate of its instruction sequence: see issue_roofline"},
+                "issue_roofline": issue,
                 "equivalent_allpairs_interactions_per_s": float(nbodies) * nbodies * bsteps / bdt}
 
     def extra(key, fn):

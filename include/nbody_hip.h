@@ -265,6 +265,15 @@ int nbody_upload_octree(nbody_ctx* ctx, const nbody_octree_node* host_nodes, uin
  * the sorted order (body index of rank r).  Any pointer may be NULL.  Requires a built tree. */
 int nbody_morton_keys(nbody_ctx* ctx, uint64_t* host_keys, uint8_t* host_leaf_depth, uint32_t* host_order);
 
+/* Tuning hook, no counterpart in the reference (whose traversal is one thread per body).  The
+ * traversal walks 64 targets per wavefront; by default those are 64 consecutive bodies of the
+ * library's own target order.  host_order (count entries; body indices, every body exactly once,
+ * 0xffffffff = a lane left empty; count in [n_bodies, 4 n_bodies + 64]) replaces that grouping for
+ * nbody_accel_bh / nbody_step_bh on an unsharded context, until it is reset with NULL.  The
+ * accelerations do not depend on the grouping, bit for bit: a lane interacts with the same nodes in
+ * the same order whoever shares its wavefront; only the time does. */
+int nbody_bh_set_target_order(nbody_ctx* ctx, const uint32_t* host_order, uint64_t count);
+
 /* Replaces the position readback of src/nbody_gpu_bh.rs:496-516 (and extends it to all state).
  * Any pointer may be NULL.  The pad lane of host_pos16 is written as 0. */
 int nbody_download(nbody_ctx* ctx, float* host_pos16, float* host_vel16, float* host_acc16);

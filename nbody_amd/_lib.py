@@ -75,6 +75,7 @@ SYMBOLS = {
     "nbody_download_octree": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "nbody_upload_octree": (C.c_int, [_P, _P, C.c_uint64]),
     "nbody_morton_keys": (C.c_int, [_P, _P, _P, _P]),
+    "nbody_bh_set_target_order": (C.c_int, [_P, _P, C.c_uint64]),
     "nbody_download": (C.c_int, [_P, _P, _P, _P]),
     "nbody_download_alt": (C.c_int, [_P, _P, _P, _P]),
     "nbody_sync": (C.c_int, [_P]),

@@ -254,6 +254,7 @@ int nbody_upload(nbody_ctx* ctx, const float* host_masses, const float* host_pos
         ctx->cur = 0;
         ctx->leapfrog_started = false;
         ctx->pending_forces = 0;
+        nb_tree_forget_order(ctx);
         ctx->mass0 = host_masses[0];
         ctx->uniform_mass = true;
         for (uint64_t i = 1; i < ctx->n && ctx->uniform_mass; ++i) ctx->uniform_mass = host_masses[i] == ctx->mass0;
@@ -528,6 +529,16 @@ int nbody_morton_keys(nbody_ctx* ctx, uint64_t* host_keys, uint8_t* host_leaf_de
         int r = set_device(ctx);
         if (r) return r;
         return nb_tree_keys(ctx, host_keys, host_leaf_depth, host_order);
+    });
+}
+
+int nbody_bh_set_target_order(nbody_ctx* ctx, const uint32_t* host_order, uint64_t count) {
+    if (!ctx) return NBODY_ERR_INVALID;
+    if (ctx->i_count != ctx->n) return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_bh_set_target_order: the context must hold all bodies (no shard range)");
+    return guarded(ctx, [&]() -> int {
+        int r = set_device(ctx);
+        if (r) return r;
+        return nb_tree_set_target_order(ctx, host_order, count);
     });
 }
 

@@ -38,6 +38,9 @@ namespace {
 constexpr int NCNT = 18;       // level counters 0..16 + leaf-list members
 constexpr int LIST_ROW = 17;
 constexpr uint32_t NO_NODE = 0xffffffffu;
+constexpr uint32_t ROPE_FLAG = 0x80000000u;
+constexpr uint32_t ROPE_END = 0x7fffffffu;
+constexpr int NWALK_COUNTERS = 24;  // 8 totals + 16 bins of wavefront visits by active lanes
 
 // Node record (32 B): written by the build, fetched by the traversal with scalar loads.
 // Breadth-first numbering makes the children of a node (octant order) and the members of a leaf
@@ -78,6 +81,17 @@ __device__ __forceinline__ void qn_set_range(QNode& nd, float range, MacScale ma
 }
 static_assert(sizeof(QNode) == 32, "node record layout");
 
+// Per node, beside its record: what the traversal needs only now and then.  `range` is the longest
+// side of the node's bounding box (src/octree_maxdepth.rs:101; read where a distance falls between
+// the two thresholds); `rope` is the node that the reference's depth-first order reaches next when
+// this node's subtree is skipped (its next sibling, else its parent's rope), ROPE_END after the
+// last node.  While the ropes are being made, ROPE_FLAG | parent stands for "the parent's rope"
+// (node ids stay below 2^31).
+struct NodeAux {
+    float range;
+    uint32_t rope;
+};
+
 }  // namespace
 
 struct Octree {
@@ -104,7 +118,7 @@ struct Octree {
     QNode* nodes = nullptr;
     float4* bmin = nullptr;          // bounding box of the bodies below each node
     float4* bmax = nullptr;
-    float* range = nullptr;          // longest side of that box (src/octree_maxdepth.rs:101)
+    NodeAux* aux = nullptr;          // longest side of that box (src/octree_maxdepth.rs:101), and the node's rope
     uint32_t* node_head = nullptr;   // sorted rank of the first body of each node's cell
     float* quad = nullptr;           // opt-in: traceless quadrupole about the node's centre of mass,
                                      // 8 floats per node {xx, xy, xz, yy, yz, zz, 0, 0}
@@ -120,7 +134,7 @@ struct Octree {
     // walk
     uint32_t* shard_blk = nullptr;   // per-workgroup counts of the compaction below, then their scan
     uint32_t* shard_order = nullptr;  // sorted ranks' body indices restricted to the shard
-    uint64_t* walk_counters = nullptr;  // [8]
+    uint64_t* walk_counters = nullptr;  // [NWALK_COUNTERS]
     uint32_t* err_flag = nullptr;
     // launch order of the traversal's wavefronts: node visits of every wavefront in the last
     // traversal, and the order (longest first within each XCD's share) made from them
@@ -129,6 +143,17 @@ struct Octree {
     uint32_t perm_nblk = 0;            // grid the order was made for (0: none)
     const uint32_t* perm_order = nullptr;  // ... and the target list it belongs to
     uint32_t perm_age = 0;
+    // caller-given grouping of the traversal's targets (nbody_bh_set_target_order): body indices,
+    // NO_NODE = an empty lane
+    uint32_t* user_order = nullptr;
+    uint64_t user_m = 0;
+    // the library's own grouping for an unsharded traversal: body indices along the Hilbert curve,
+    // made from a build's sorted keys and kept for HILBERT_KEEP builds (bodies move little per step,
+    // and any permutation of the bodies is a valid grouping)
+    uint32_t* hkeys[2] = {nullptr, nullptr};
+    uint32_t* hidx[2] = {nullptr, nullptr};
+    const uint32_t* horder = nullptr;  // hidx[0] or hidx[1] once made
+    uint32_t horder_age = 0;           // builds since it was made
 };
 
 namespace {
@@ -160,6 +185,59 @@ __global__ void k_morton(const float4* __restrict__ posm, uint32_t n, float worl
     idx[i] = i;
 }
 
+// ---- 1b. Hilbert keys (grouping of the traversal's targets) ----------------------------------
+// The position of a body's depth-L cell on the Hilbert curve through the root cube (Skilling's
+// transform of the cell coordinates, which the Morton key holds bit-interleaved).  Like the Morton
+// order it keeps every octree cell contiguous; unlike it, consecutive cells are always neighbours,
+// so 64 consecutive bodies make a more compact group.  No counterpart in the reference, whose
+// traversal is one thread per body.
+__device__ __forceinline__ uint32_t hilbert_from_morton(uint64_t key, int D, int L) {
+    uint32_t X[3] = {0u, 0u, 0u};
+    for (int l = 0; l < D; ++l) {
+        const uint32_t d = (uint32_t)(key >> (3 * (D - 1 - l))) & 7u;
+        X[0] = (X[0] << 1) | ((d >> 2) & 1u);
+        X[1] = (X[1] << 1) | ((d >> 1) & 1u);
+        X[2] = (X[2] << 1) | (d & 1u);
+    }
+    for (uint32_t Q = 1u << (D - 1); Q > 1u; Q >>= 1) {
+        const uint32_t P = Q - 1u;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (X[i] & Q) {
+                X[0] ^= P;
+            } else {
+                const uint32_t t = (X[0] ^ X[i]) & P;
+                X[0] ^= t;
+                X[i] ^= t;
+            }
+        }
+    }
+    X[1] ^= X[0];
+    X[2] ^= X[1];
+    uint32_t t = 0u;
+    for (uint32_t Q = 1u << (D - 1); Q > 1u; Q >>= 1)
+        if (X[2] & Q) t ^= Q - 1u;
+    X[0] ^= t;
+    X[1] ^= t;
+    X[2] ^= t;
+    uint32_t h = 0u;  // the top L levels: 3 L <= 30 bits
+    for (int b = D - 1; b >= D - L; --b) {
+        h = (h << 1) | ((X[0] >> b) & 1u);
+        h = (h << 1) | ((X[1] >> b) & 1u);
+        h = (h << 1) | ((X[2] >> b) & 1u);
+    }
+    return h;
+}
+
+// Per sorted rank: the Hilbert key of the body's cell and the body's index (the sort's payload).
+__global__ void k_hilbert(const uint64_t* __restrict__ keys_sorted, const uint32_t* __restrict__ idx_sorted, uint32_t n, int D,
+                          int L, uint32_t* __restrict__ hkeys, uint32_t* __restrict__ hidx) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    hkeys[r] = hilbert_from_morton(keys_sorted[r], D, L);
+    hidx[r] = idx_sorted[r];
+}
+
 // ---- 2. LSD radix sort, 8-bit digits ------------------------------------------------------
 constexpr int RS_THREADS = 256;
 constexpr int RS_WAVES = RS_THREADS / 64;
@@ -167,7 +245,8 @@ constexpr int RS_ITEMS = 16;
 constexpr int RS_TILE = RS_THREADS * RS_ITEMS;  // items of one workgroup: wavefront w owns [w, w+1) * RS_TILE / RS_WAVES
 constexpr int RS_WTILE = RS_TILE / RS_WAVES;
 
-__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint64_t* __restrict__ keys, uint32_t n, int shift,
+template <class K>
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const K* __restrict__ keys, uint32_t n, int shift,
                                                         uint32_t* __restrict__ counts, uint32_t nb) {
     __shared__ uint32_t h[256];
     const int tid = threadIdx.x;
@@ -245,15 +324,16 @@ __global__ __launch_bounds__(256) void k_scan_small(const uint32_t* __restrict__
 // One tile: rank every item among the tile's items of the same digit (stable: wavefront-major,
 // then load order, then lane), stage the tile in LDS in digit order, then write each digit's run
 // to its place in the output with consecutive lanes on consecutive addresses.
-__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t* __restrict__ keys_in,
+template <class K>
+__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const K* __restrict__ keys_in,
                                                            const uint32_t* __restrict__ idx_in,
-                                                           uint64_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out,
+                                                           K* __restrict__ keys_out, uint32_t* __restrict__ idx_out,
                                                            uint32_t n, int shift, const uint32_t* __restrict__ counts,
                                                            const uint32_t* __restrict__ row_total, uint32_t nb) {
     __shared__ uint32_t wcnt[RS_WAVES][256];  // per-wavefront digit counts, then tile-local offsets
     __shared__ uint32_t gbase[256];           // output position of staged item j of digit d = gbase[d] + j
     __shared__ uint32_t wsum[RS_WAVES], gsum[RS_WAVES];
-    __shared__ uint64_t skey[RS_TILE];
+    __shared__ K skey[RS_TILE];
     __shared__ uint32_t sval[RS_TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #pragma unroll
@@ -262,7 +342,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t* __res
     const uint32_t tile0 = blockIdx.x * RS_TILE;
     const uint32_t wbase = tile0 + wave * RS_WTILE;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    uint64_t key[RS_ITEMS];
+    K key[RS_ITEMS];
     uint32_t val[RS_ITEMS], rnk[RS_ITEMS];
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; ++it) {
@@ -352,7 +432,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t* __res
     __syncthreads();
     const uint32_t cnt = min((uint32_t)RS_TILE, n - tile0);
     for (uint32_t j = tid; j < cnt; j += RS_THREADS) {
-        const uint64_t k = skey[j];
+        const K k = skey[j];
         const uint32_t pos = gbase[(uint32_t)(k >> shift) & 255u] + j;
         keys_out[pos] = k;
         idx_out[pos] = sval[j];
@@ -410,7 +490,7 @@ __global__ __launch_bounds__(256) void k_emit(const uint64_t* __restrict__ keys,
                                               const uint8_t* __restrict__ lo, const uint8_t* __restrict__ top,
                                               const uint8_t* __restrict__ flags, const uint32_t* __restrict__ blk,
                                               uint32_t nb, const uint32_t* __restrict__ lvl_start, QNode* __restrict__ nodes,
-                                              float4* __restrict__ bmin, float4* __restrict__ bmax, float* __restrict__ range,
+                                              float4* __restrict__ bmin, float4* __restrict__ bmax, NodeAux* __restrict__ aux,
                                               uint32_t* __restrict__ node_head, uint32_t* __restrict__ body_node,
                                               uint32_t cap_nodes, uint32_t* __restrict__ err_flag) {
     __shared__ uint32_t wtot[NCNT][4];
@@ -486,7 +566,7 @@ __global__ __launch_bounds__(256) void k_emit(const uint64_t* __restrict__ keys,
 __global__ void k_leaflist(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idx,
                            const float4* __restrict__ posm, uint32_t n, int list_mode, const uint8_t* __restrict__ flags,
                            const uint32_t* __restrict__ body_node, QNode* __restrict__ nodes, float4* __restrict__ bmin,
-                           float4* __restrict__ bmax, float* __restrict__ range, uint32_t* __restrict__ node_head,
+                           float4* __restrict__ bmax, NodeAux* __restrict__ aux, uint32_t* __restrict__ node_head,
                            uint32_t cap_nodes, MacScale mac) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || !(flags[i] & 2u)) return;
@@ -507,6 +587,7 @@ __global__ void k_leaflist(const uint64_t* __restrict__ keys, const uint32_t* __
             c.count_type = qn_pack(0, NBODY_NODE_LEAFBODY);
             nodes[member] = c;
             node_head[member] = i;
+            aux[member].rope = member + 1;  // the next member; the last one is redirected below
         }
         ++member;
         ++count;
@@ -528,8 +609,9 @@ __global__ void k_leaflist(const uint64_t* __restrict__ keys, const uint32_t* __
     const float rg = fmaxf(mxx - mnx, fmaxf(mxy - mny, mxz - mnz));
     qn_set_range(nd, rg, mac);
     nd.count_type = qn_pack(count, NBODY_NODE_LEAFLIST);
+    if (count && member - 1 < cap_nodes) aux[member - 1].rope = ROPE_FLAG | id;  // after the last member: wherever the cell's rope leads
     nodes[id] = nd;
-    range[id] = rg;
+    aux[id].range = rg;
     bmin[id] = make_float4(mnx, mny, mnz, 0.0f);
     bmax[id] = make_float4(mxx, mxy, mxz, 0.0f);
 }
@@ -538,13 +620,19 @@ __global__ void k_leaflist(const uint64_t* __restrict__ keys, const uint32_t* __
 // One level: nodes [first_id, first_id + count).  The children of a node end where the next
 // node's begin (`child_end` for the last node of the level).
 __global__ void k_aggregate(QNode* __restrict__ nodes, float4* __restrict__ bmin, float4* __restrict__ bmax,
-                            float* __restrict__ range, uint32_t first_id, uint32_t count, uint32_t child_end, MacScale mac) {
+                            NodeAux* __restrict__ aux, uint32_t first_id, uint32_t count, uint32_t child_end, MacScale mac) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= count) return;
     const uint32_t id = first_id + r;
+    if (id == 0) aux[0].rope = ROPE_END;  // nothing follows the root
     QNode nd = nodes[id];
     if (qn_type(nd) != NBODY_NODE_INTERIOR) return;
     const uint32_t c0 = nd.first, c1 = (r + 1 < count) ? nodes[id + 1].first : child_end;
+    // ropes of the children: the next sibling; after the last child, wherever this node's rope leads
+    // (resolved by k_rope_resolve once every level has written its links)
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (c0 + k < c1) aux[c0 + k].rope = (c0 + k + 1 < c1) ? c0 + k + 1 : (ROPE_FLAG | id);
     // An interior node has at most eight children: all their records (and the boxes of those that
     // are cells themselves) are requested before the first is used; the sums then run in child
     // order, as a loop over the children would.
@@ -584,9 +672,25 @@ __global__ void k_aggregate(QNode* __restrict__ nodes, float4* __restrict__ bmin
     qn_set_range(nd, rg, mac);
     nd.count_type = qn_pack(c1 - c0, NBODY_NODE_INTERIOR);
     nodes[id] = nd;
-    range[id] = rg;
+    aux[id].range = rg;
     bmin[id] = make_float4(mnx, mny, mnz, 0.0f);
     bmax[id] = make_float4(mxx, mxy, mxz, 0.0f);
+}
+
+// Replaces every "my parent's rope" link by the node it stands for.  A thread follows the chain
+// of last children upward until it meets a resolved rope; links that other threads resolve in the
+// meantime are read either way (old: one more hop, new: the answer), with the same result.
+__global__ void k_rope_resolve(NodeAux* aux, uint32_t count) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= count) return;
+    uint32_t r = aux[id].rope;
+    if (!(r & ROPE_FLAG)) return;
+    for (int hop = 0; hop < 64 && (r & ROPE_FLAG); ++hop) {
+        const uint32_t up = r & ~ROPE_FLAG;
+        if (up >= count) break;  // (never: a link names an existing node)
+        r = aux[up].rope;
+    }
+    aux[id].rope = (r & ROPE_FLAG) ? ROPE_END : r;  // (a chain longer than any tree has levels: end the traversal there)
 }
 
 // ---- 7b. quadrupole moments (opt-in, no counterpart in the reference) -----------------------
@@ -629,7 +733,7 @@ __global__ void k_quadrupole(const QNode* __restrict__ nodes, float* __restrict_
 
 // ---- export / import (96-byte reference layout) ---------------------------------------------
 __global__ void k_export(const QNode* __restrict__ nodes, const float4* __restrict__ bmin, const float4* __restrict__ bmax,
-                         const float* __restrict__ range, const uint32_t* __restrict__ node_head, const uint64_t* __restrict__ keys,
+                         const NodeAux* __restrict__ aux, const uint32_t* __restrict__ node_head, const uint64_t* __restrict__ keys,
                          const uint32_t* __restrict__ lvl_start, int D, uint32_t count, int octree_rs,
                          nbody_octree_node* __restrict__ out) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
@@ -644,7 +748,7 @@ __global__ void k_export(const QNode* __restrict__ nodes, const float4* __restri
     o.center_of_mass[0] = nd.cx; o.center_of_mass[1] = nd.cy; o.center_of_mass[2] = nd.cz; o._pad0 = 0.0f;
     o.pos_min[0] = lo.x; o.pos_min[1] = lo.y; o.pos_min[2] = lo.z; o._pad1 = 0.0f;
     o.pos_max[0] = hi.x; o.pos_max[1] = hi.y; o.pos_max[2] = hi.z;
-    o.range = leaf ? 0.0f : range[id];
+    o.range = leaf ? 0.0f : aux[id].range;
     o.total_mass = nd.mass;
     for (int k = 0; k < 8; ++k) o.child_indices[k] = 0;
     const uint32_t type = qn_type(nd), cnt = qn_count(nd);
@@ -676,10 +780,11 @@ __global__ void k_export(const QNode* __restrict__ nodes, const float4* __restri
 
 // Uploaded trees arrive renumbered breadth-first by the host: children consecutive in octant order.
 __global__ void k_import(const nbody_octree_node* __restrict__ in, uint32_t count, QNode* __restrict__ nodes,
-                         float4* __restrict__ bmin, float4* __restrict__ bmax, float* __restrict__ range, MacScale mac,
+                         float4* __restrict__ bmin, float4* __restrict__ bmax, NodeAux* __restrict__ aux, MacScale mac,
                          uint32_t* __restrict__ err_flag) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= count) return;
+    if (id == 0) aux[0].rope = ROPE_END;
     const nbody_octree_node o = in[id];
     QNode nd;
     nd.cx = o.center_of_mass[0]; nd.cy = o.center_of_mass[1]; nd.cz = o.center_of_mass[2];
@@ -703,8 +808,11 @@ __global__ void k_import(const nbody_octree_node* __restrict__ in, uint32_t coun
         cnt = max(o.child_indices[1], 1u);  // src/nbodybh.wgsl:139-146 is a do-while: at least one member
     }
     nd.count_type = qn_pack(cnt, o.node_type);
+    // ropes of the children / members (consecutive after the host's renumbering)
+    for (uint32_t c = 0; c < cnt && nd.first + c < count; ++c)
+        aux[nd.first + c].rope = (c + 1 < cnt) ? nd.first + c + 1 : (ROPE_FLAG | id);
     nodes[id] = nd;
-    range[id] = o.range;
+    aux[id].range = o.range;
     bmin[id] = make_float4(o.pos_min[0], o.pos_min[1], o.pos_min[2], 0.0f);
     bmax[id] = make_float4(o.pos_max[0], o.pos_max[1], o.pos_max[2], 0.0f);
 }
@@ -772,6 +880,15 @@ constexpr bool WALK_PRECISE = false;  // one Newton step on v_rsq_f32 in the tra
 constexpr int WALK_STACK = 160;  // >= 8 pushes per level x 17 levels + root
 constexpr int WALK_THREADS = 64;  // one wavefront per workgroup: its slot is refilled as soon as it ends (3 % over 256)
 constexpr int WALK_BATCH = 8;    // node records fetched together; the node array is padded by as many
+constexpr int HILBERT_LEVELS = 10;      // levels of the octree the Hilbert keys resolve (30 bits, four sort passes)
+constexpr uint32_t HILBERT_KEEP = 16;   // builds after which the order is made afresh
+constexpr uint64_t HILBERT_MIN_N = 32768;  // below this the sort costs more than the grouping saves
+constexpr int DEFER_SLOTS = 12;  // nodes a lane can note for its own second-phase walk (LDS: 4 B x 64 lanes each)
+#ifndef NBODY_WALK_DEFER_LANES
+#define NBODY_WALK_DEFER_LANES 12
+#endif
+constexpr int WALK_DEFER_LANES = NBODY_WALK_DEFER_LANES;  // a node opened by at most this many lanes is left to their own walks (0: never)
+
 
 // The lanes for which p holds, as a wave-uniform value the compiler keeps in scalar registers
 // (without the empty asm it folds "ballot != 0" back into a per-lane test).
@@ -803,16 +920,21 @@ __device__ __forceinline__ void pin_moment(const QMoment& m) {
 // remainder on the stack.
 // Seven wavefronts per SIMD (at most 96 scalar registers): measured 4 % faster at N = 16M than the
 // six the unconstrained allocation is admitted with; eight (80) spills and is twice as slow.
-template <int LAW, bool COUNT, bool QUAD>
+template <int LAW, bool COUNT, bool QUAD, int DEFER_LANES>
 __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_walk(const QNode* __restrict__ q, const uint32_t* __restrict__ order, uint32_t m,
                                               uint32_t i_begin, const float4* __restrict__ posm,
                                               const float4* __restrict__ vel, float4* __restrict__ acc_out, float G,
-                                              float eps2, float theta, const float* __restrict__ range,
+                                              float eps2, float theta, const NodeAux* __restrict__ aux,
                                               unsigned long long* __restrict__ counters,
                                               uint32_t* __restrict__ err_flag, int out_by_rank,
                                               const float* __restrict__ quad, const uint32_t* __restrict__ perm,
-                                              uint32_t* __restrict__ wave_cost) {
+                                              uint32_t* __restrict__ wave_cost, uint32_t n_nodes) {
     __shared__ uint4 stack[WALK_STACK];  // {first, count, mask.lo, mask.hi}
+    // Nodes that only a few lanes open are not walked by the whole wavefront: each of those lanes
+    // notes the node here and walks its subtree by itself afterwards (second phase below).
+    __shared__ uint32_t dlist[DEFER_SLOTS][WALK_THREADS];
+    constexpr bool DEFER = !QUAD && DEFER_LANES > 0;
+    uint32_t n_def = 0;
     const int lane = threadIdx.x;
     // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2): give each XCD one
     // contiguous eighth of the Morton order, so that it keeps meeting the same part of the tree.
@@ -821,8 +943,9 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(7,
     const uint32_t xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
     const uint32_t blk = perm ? perm[blockIdx.x] : xcd * q8 + min(xcd, r8) + slot;
     const uint32_t r = blk * WALK_THREADS + lane;
-    const bool valid = r < m;
-    const uint32_t b = valid ? (order ? order[r] : i_begin + r) : 0u;
+    uint32_t b = r < m ? (order ? order[r] : i_begin + r) : NO_NODE;
+    const bool valid = b != NO_NODE;  // (a caller-given order may leave lanes empty)
+    if (!valid) b = 0u;
     Tgt t;
     {
         const float4 p = posm[b];
@@ -880,6 +1003,8 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(7,
         }
         __builtin_assume(cnt >= 1);
         n_wave += cnt;
+        // (counting build) wavefront visits by the number of lanes they are made for, in 16 steps of 4
+        if (COUNT && lane == 0) atomicAdd(&counters[8 + ((int)__popcll(mask) - 1) / 4], (unsigned long long)cnt);
         // Inside this branch EXEC is the group's lane set.  The stack pointer is advanced by those
         // lanes only (to the compiler it is a per-lane value there) and read back from one of them.
         int top_v = top;
@@ -939,11 +1064,23 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(7,
                     unsigned long long open = rest;
                     const unsigned long long unsure = rest & lanes(!(r2 < nd.r2_open));
                     if (unsure) {
-                        const float rg = range[first + k];
+                        const float rg = aux[first + k].range;
                         const float rr = sqrtf(((dx * dx) + (dy * dy)) + (dz * dz));  // distance(pos, com)
                         open &= ~(unsure & lanes((rg / rr) < theta));
                     }
-                    if (open && qn_count(nd)) {  // (an empty group is never pushed: a popped group has >= 1 record)
+                    bool deferred = false;
+                    if (DEFER && open && qn_type(nd) == NBODY_NODE_INTERIOR && (uint32_t)__popcll(open) <= (uint32_t)DEFER_LANES) {
+                        // few lanes open it: each takes the subtree for itself, if all of them have room to note it
+                        const bool mine = __builtin_amdgcn_inverse_ballot_w64(open);
+                        if (lanes(mine && n_def >= (uint32_t)DEFER_SLOTS) == 0) {
+                            if (mine) {
+                                dlist[n_def][lane] = first + k;
+                                ++n_def;
+                            }
+                            deferred = true;
+                        }
+                    }
+                    if (open && qn_count(nd) && !deferred) {  // (an empty group is never pushed: a popped group has >= 1 record)
                         // INTERIOR: its children; LEAFLIST: its members (LEAFBODY records, src/nbodybh.wgsl:137-146)
                         if (top_v < WALK_STACK) {
                             stack[top_v] = make_uint4(nd.first, qn_count(nd), (uint32_t)open, (uint32_t)(open >> 32));
@@ -985,6 +1122,70 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(7,
         }
         top = __builtin_amdgcn_readlane(top_v, (int)__builtin_ctzll(mask));
         if (COUNT) max_top = max(max_top, (uint32_t)top);  // pushes only grow the stack within a batch
+    }
+    if (DEFER) {
+        // Second phase: every lane walks the subtrees it noted, by itself -- one record per step, its own
+        // record (vector loads), no stack: where a node is taken or skipped the walk goes on at rope[node],
+        // where it is opened at its first child; a noted node's subtree ends where that node's own rope
+        // leads.  The decisions are those of the first phase (src/nbodybh.wgsl:76-134), so a lane still
+        // meets exactly the nodes of the reference's traversal; only the order of its sum changes.
+        uint32_t cur = ROPE_END, end = ROPE_END;
+        uint32_t steps = 0;
+        for (;;) {
+            if (cur == end && n_def > 0) {
+                --n_def;
+                const uint32_t p = dlist[n_def][lane];  // (a node this lane noted itself: always a valid index)
+                cur = q[p].first;
+                end = aux[p].rope;
+            }
+            bool active = cur != end;
+            if (active && cur >= n_nodes) {  // (never, with the links the build makes: a broken link ends the lane's walk)
+                *err_flag = 4;
+                cur = end;
+                active = false;
+            }
+            const unsigned long long act = lanes(active);
+            if (act == 0) break;
+            if (++steps > n_nodes) {  // (a lane meets a node at most once: more steps than nodes means links in a circle)
+                *err_flag = 4;
+                break;
+            }
+            n_wave += 1;
+            if (COUNT && lane == 0) atomicAdd(&counters[8 + ((int)__popcll(act) - 1) / 4], 1ull);
+            if (active) {
+                const QNode nd = q[cur];
+                const NodeAux na = aux[cur];
+                const uint32_t next = na.rope;
+                if (COUNT) ++n_visit;
+                const float dx = nd.cx - t.x, dy = nd.cy - t.y, dz = nd.cz - t.z;
+                const float r2 = LAW == NBODY_LAW_PLUMMER ? fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, eps2)))
+                                                          : fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+                bool open = false;
+                if (!(r2 > nd.r2_accept) && qn_type(nd) != NBODY_NODE_LEAFBODY) {
+                    open = r2 < nd.r2_open;
+                    if (!open) {  // between the thresholds: the reference's own expression
+                        const float rr = sqrtf(((dx * dx) + (dy * dy)) + (dz * dz));
+                        open = !((na.range / rr) < theta);
+                    }
+                }
+                if (COUNT && !open) {
+                    if (qn_type(nd) == NBODY_NODE_LEAFBODY) ++n_leaf;
+                    else ++n_agg;
+                }
+                float sc;
+                if (LAW == NBODY_LAW_PLUMMER) {
+                    const float ri = WALK_PRECISE ? rsq_refined(r2) : __builtin_amdgcn_rsqf(r2);
+                    sc = (nd.mass * ri) * (ri * ri);
+                } else {
+                    sc = pair_scale<LAW, WALK_PRECISE>(t, dx, dy, dz, r2, nd.mass, eps2);
+                }
+                const float w = open ? 0.0f : sc;
+                ax = fmaf(w, dx, ax);
+                ay = fmaf(w, dy, ay);
+                az = fmaf(w, dz, az);
+                cur = (open && qn_count(nd)) ? nd.first : next;
+            }
+        }
     }
     if (valid) acc_out[out_by_rank ? i_begin + r : b] = make_float4(G * ax, G * ay, G * az, 0.0f);
     if (wave_cost && lane == 0) wave_cost[blk] = n_wave;
@@ -1034,6 +1235,11 @@ __global__ __launch_bounds__(1024) void k_walk_order(const uint32_t* __restrict_
 
 // theta == 0 gives infinite (or, for a zero range, NaN) thresholds: nothing is accepted by
 // them and the reference's expression, evaluated in the band, opens every node as it should.
+int env_int_or(const char* name, int dflt) {
+    const char* v = std::getenv(name);
+    return (v && *v) ? std::atoi(v) : dflt;
+}
+
 MacScale mac_scale(const nbody_ctx* ctx) {
     const float th2 = ctx->cfg.theta * ctx->cfg.theta;
     const float soft = ctx->cfg.law == NBODY_LAW_PLUMMER ? ctx->cfg.eps2 : 0.0f;
@@ -1045,8 +1251,9 @@ MacScale mac_scale(const nbody_ctx* ctx) {
 int ensure_nodes(nbody_ctx* ctx, Octree* T, uint64_t need) {
     if (need <= T->cap_nodes) return NBODY_OK;
     uint64_t cap = std::max<uint64_t>(need + need / 4 + 1024, 2 * T->n + 1024);
-    if (cap > 0xfffffff0ull) return nb_fail(ctx, NBODY_ERR_CAPACITY, "octree needs more than 2^32 nodes");
-    void** arrays[] = {(void**)&T->nodes, (void**)&T->node_head, (void**)&T->bmin, (void**)&T->bmax, (void**)&T->range, (void**)&T->quad};
+    if (need >= ROPE_END) return nb_fail(ctx, NBODY_ERR_CAPACITY, "octree needs more than 2^31 nodes");
+    cap = std::min<uint64_t>(cap, ROPE_END);
+    void** arrays[] = {(void**)&T->nodes, (void**)&T->node_head, (void**)&T->bmin, (void**)&T->bmax, (void**)&T->aux, (void**)&T->quad};
     for (void** a : arrays) {
         if (*a) (void)hipFree(*a);
         *a = nullptr;
@@ -1055,7 +1262,7 @@ int ensure_nodes(nbody_ctx* ctx, Octree* T, uint64_t need) {
     T->have_tree = false;
     // the traversal fetches whole batches: pad so that the last group's batch stays inside
     hipError_t e = hipMalloc(&T->nodes, (cap + WALK_BATCH) * sizeof(QNode));
-    if (e == hipSuccess) e = hipMalloc(&T->range, cap * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&T->aux, cap * sizeof(NodeAux));
     if (e == hipSuccess && ctx->cfg.quadrupole) e = hipMalloc(&T->quad, (cap + WALK_BATCH) * 8 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&T->node_head, cap * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&T->bmin, cap * sizeof(float4));
@@ -1081,6 +1288,7 @@ int check_err_flag(nbody_ctx* ctx, Octree* T, const char* what) {
         return nb_fail(ctx, NBODY_ERR_CAPACITY,
                        std::string(what) + (h == 2 ? ": traversal stack overflow"
                                             : h == 3 ? ": children of a node are not consecutive"
+                                            : h == 4 ? ": a lane's own walk did not end (broken node links)"
                                                      : ": node capacity exceeded"));
     }
     return NBODY_OK;
@@ -1097,9 +1305,9 @@ void launch_walk(nbody_ctx* ctx, Octree* T, const uint32_t* order, uint32_t m, c
     const uint32_t* perm = ordered && T->perm_nblk == grid.x && T->perm_order == order ? T->wave_perm : nullptr;
     uint32_t* cost = ordered ? T->wave_cost : nullptr;
 #define NB_WALK(COUNT, QUAD)                                                                                              \
-    hipLaunchKernelGGL((k_walk<LAW, COUNT, QUAD>), grid, dim3(WALK_THREADS), 0, ctx->stream, T->nodes, order, m, i_begin, posm, \
-                       vel, acc_out, ctx->cfg.G, ctx->cfg.eps2, ctx->cfg.theta, T->range,                                 \
-                       (unsigned long long*)T->walk_counters, T->err_flag, out_by_rank, T->quad, perm, cost)
+    hipLaunchKernelGGL((k_walk<LAW, COUNT, QUAD, WALK_DEFER_LANES>), grid, dim3(WALK_THREADS), 0, ctx->stream, T->nodes, order, m, i_begin, posm, \
+                       vel, acc_out, ctx->cfg.G, ctx->cfg.eps2, ctx->cfg.theta, T->aux,                                 \
+                       (unsigned long long*)T->walk_counters, T->err_flag, out_by_rank, T->quad, perm, cost, (uint32_t)T->n_nodes)
     if (ctx->counting) {
         if (quad) { NB_WALK(true, true); }
         else { NB_WALK(true, false); }
@@ -1151,7 +1359,7 @@ int nb_tree_create(nbody_ctx* ctx) {
     NB_HIP(ctx, hipMalloc(&T->lvl_start, (NCNT + 1) * sizeof(uint32_t)));
     NB_HIP(ctx, hipHostMalloc(&T->h_lvl_start, (NCNT + 1) * sizeof(uint32_t), hipHostMallocDefault));
     NB_HIP(ctx, hipEventCreateWithFlags(&T->lvl_ready, hipEventDisableTiming));
-    NB_HIP(ctx, hipMalloc(&T->walk_counters, 8 * sizeof(uint64_t)));
+    NB_HIP(ctx, hipMalloc(&T->walk_counters, NWALK_COUNTERS * sizeof(uint64_t)));
     NB_HIP(ctx, hipMalloc(&T->wave_cost, 8 * ORDER_MAX * sizeof(uint32_t)));
     NB_HIP(ctx, hipMalloc(&T->wave_perm, 8 * ORDER_MAX * sizeof(uint32_t)));
     NB_HIP(ctx, hipMalloc(&T->err_flag, sizeof(uint32_t)));
@@ -1170,9 +1378,13 @@ void nb_tree_destroy(nbody_ctx* ctx) {
         if (T->keys[s]) hipFree(T->keys[s]);
         if (T->idx[s]) hipFree(T->idx[s]);
     }
+    for (int k = 0; k < 2; ++k) {
+        if (T->hkeys[k]) (void)hipFree(T->hkeys[k]);
+        if (T->hidx[k]) (void)hipFree(T->hidx[k]);
+    }
     void* ptrs[] = {T->lo, T->top, T->flags, T->body_node, T->rs_counts, T->row_total, T->blk,
-                    T->lvl_total, T->lvl_start, T->nodes, T->node_head, T->bmin, T->bmax, T->range, T->quad, T->export_buf, T->shard_order, T->shard_blk,
-                    T->walk_counters, T->err_flag, T->wave_cost, T->wave_perm};
+                    T->lvl_total, T->lvl_start, T->nodes, T->node_head, T->bmin, T->bmax, T->aux, T->quad, T->export_buf, T->shard_order, T->shard_blk,
+                    T->walk_counters, T->err_flag, T->wave_cost, T->wave_perm, T->user_order};
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (T->h_lvl_start) hipHostFree(T->h_lvl_start);
@@ -1194,9 +1406,9 @@ int nb_tree_build(nbody_ctx* ctx, const float4* posm_in) {
     int cur = 0;
     const int bits = 3 * D;
     for (int shift = 0; shift < bits; shift += 8) {
-        hipLaunchKernelGGL(k_rs_hist, dim3(T->rs_nb), dim3(RS_THREADS), 0, st, T->keys[cur], n, shift, T->rs_counts, T->rs_nb);
+        hipLaunchKernelGGL(k_rs_hist<uint64_t>, dim3(T->rs_nb), dim3(RS_THREADS), 0, st, T->keys[cur], n, shift, T->rs_counts, T->rs_nb);
         hipLaunchKernelGGL(k_rowscan, dim3(256), dim3(256), 0, st, T->rs_counts, T->rs_nb, T->row_total);
-        hipLaunchKernelGGL(k_rs_scatter, dim3(T->rs_nb), dim3(RS_THREADS), 0, st, T->keys[cur], T->idx[cur], T->keys[cur ^ 1],
+        hipLaunchKernelGGL(k_rs_scatter<uint64_t>, dim3(T->rs_nb), dim3(RS_THREADS), 0, st, T->keys[cur], T->idx[cur], T->keys[cur ^ 1],
                            T->idx[cur ^ 1], n, shift, T->rs_counts, T->row_total, T->rs_nb);
         NB_HIP(ctx, hipGetLastError());
         cur ^= 1;
@@ -1214,7 +1426,7 @@ int nb_tree_build(nbody_ctx* ctx, const float4* posm_in) {
     NB_HIP(ctx, hipEventRecord(T->lvl_ready, st));
     auto emit = [&]() {
         hipLaunchKernelGGL(k_emit, dim3(T->pf_nb), dim3(256), 0, st, T->keys[cur], T->idx[cur], posm_in, n, D, T->lo, T->top,
-                           T->flags, T->blk, T->pf_nb, T->lvl_start, T->nodes, T->bmin, T->bmax, T->range, T->node_head,
+                           T->flags, T->blk, T->pf_nb, T->lvl_start, T->nodes, T->bmin, T->bmax, T->aux, T->node_head,
                            T->body_node, (uint32_t)T->cap_nodes, T->err_flag);
     };
     emit();
@@ -1241,7 +1453,7 @@ int nb_tree_build(nbody_ctx* ctx, const float4* posm_in) {
     }
     if (T->h_lvl_start[LIST_ROW + 1] > T->h_lvl_start[LIST_ROW] || T->h_lvl_start[D + 1] > T->h_lvl_start[D]) {
         hipLaunchKernelGGL(k_leaflist, dim3((n + 255) / 256), dim3(256), 0, st, T->keys[cur], T->idx[cur], posm_in, n,
-                           ctx->cfg.leaflist_mode, T->flags, T->body_node, T->nodes, T->bmin, T->bmax, T->range, T->node_head,
+                           ctx->cfg.leaflist_mode, T->flags, T->body_node, T->nodes, T->bmin, T->bmax, T->aux, T->node_head,
                            (uint32_t)T->cap_nodes, mac);
         NB_HIP(ctx, hipGetLastError());
     }
@@ -1249,9 +1461,10 @@ int nb_tree_build(nbody_ctx* ctx, const float4* posm_in) {
         const uint32_t first = T->h_lvl_start[d], count = T->h_lvl_start[d + 1] - first;
         if (!count) continue;
         // the children of level d are the nodes of level d + 1
-        hipLaunchKernelGGL(k_aggregate, dim3((count + 255) / 256), dim3(256), 0, st, T->nodes, T->bmin, T->bmax, T->range, first,
-                           count, T->h_lvl_start[d + 2], mac);
+        hipLaunchKernelGGL(k_aggregate, dim3((count + 255) / 256), dim3(256), 0, st, T->nodes, T->bmin, T->bmax, T->aux,
+                           first, count, T->h_lvl_start[d + 2], mac);
     }
+    hipLaunchKernelGGL(k_rope_resolve, dim3(((uint32_t)total + 255) / 256), dim3(256), 0, st, T->aux, (uint32_t)total);
     if (T->quad) {
         for (int d = D; d >= 0; --d) {
             const uint32_t first = T->h_lvl_start[d], count = T->h_lvl_start[d + 1] - first;
@@ -1265,6 +1478,7 @@ int nb_tree_build(nbody_ctx* ctx, const float4* posm_in) {
     T->have_tree = true;
     T->built = true;
     T->export_is_upload = false;
+    ++T->horder_age;
     ctx->counters.octree_nodes = total;
     return NBODY_OK;
 }
@@ -1272,7 +1486,7 @@ int nb_tree_build(nbody_ctx* ctx, const float4* posm_in) {
 static int walk_launch(nbody_ctx* ctx, Octree* T, const uint32_t* order, uint32_t m, const float4* posm_in,
                        const float4* vel_in, float4* acc_out, uint32_t i_begin, int out_by_rank) {
     hipStream_t st = ctx->stream;
-    if (ctx->counting) NB_HIP(ctx, hipMemsetAsync(T->walk_counters, 0, 8 * sizeof(uint64_t), st));
+    if (ctx->counting) NB_HIP(ctx, hipMemsetAsync(T->walk_counters, 0, NWALK_COUNTERS * sizeof(uint64_t), st));
     nb_time_begin(ctx, 1);
     if (ctx->cfg.law == NBODY_LAW_WGSL_BIAS)
         launch_walk<NBODY_LAW_WGSL_BIAS>(ctx, T, order, m, posm_in, vel_in, acc_out, i_begin, out_by_rank);
@@ -1281,9 +1495,16 @@ static int walk_launch(nbody_ctx* ctx, Octree* T, const uint32_t* order, uint32_
     nb_time_end(ctx, 1);
     NB_HIP(ctx, hipGetLastError());
     if (ctx->counting) {
-        uint64_t h[8];
+        uint64_t h[NWALK_COUNTERS];
         NB_HIP(ctx, hipMemcpyAsync(h, T->walk_counters, sizeof h, hipMemcpyDeviceToHost, st));
         NB_HIP(ctx, hipStreamSynchronize(st));
+        if (const char* dump = std::getenv("NBODY_WALK_HIST")) {  // measurement aid: the 16 bins, to stderr
+            if (*dump == '1') {
+                std::fprintf(stderr, "walk lanes-per-visit histogram (bins of 4 lanes):");
+                for (int b = 0; b < 16; ++b) std::fprintf(stderr, " %llu", (unsigned long long)h[8 + b]);
+                std::fprintf(stderr, "\n");
+            }
+        }
         ctx->counters.bh_node_visits = h[0];
         ctx->counters.bh_leaf_interactions = h[1];
         ctx->counters.bh_aggregate_interactions = h[2];
@@ -1294,6 +1515,39 @@ static int walk_launch(nbody_ctx* ctx, Octree* T, const uint32_t* order, uint32_
     return NBODY_OK;
 }
 
+// Body indices along the Hilbert curve (stable among the bodies of one depth-HILBERT_LEVELS cell, which
+// keep their Morton order), from the keys and order of the present build.
+static int make_hilbert_order(nbody_ctx* ctx, Octree* T) {
+    const uint32_t n = (uint32_t)T->n;
+    hipStream_t st = ctx->stream;
+    if (!T->hkeys[0]) {
+        for (int k = 0; k < 2; ++k) {
+            NB_HIP(ctx, hipMalloc(&T->hkeys[k], (size_t)n * sizeof(uint32_t)));
+            NB_HIP(ctx, hipMalloc(&T->hidx[k], (size_t)n * sizeof(uint32_t)));
+        }
+    }
+    const int D = (int)T->D, L = std::min(D, HILBERT_LEVELS);
+    hipLaunchKernelGGL(k_hilbert, dim3((n + 255) / 256), dim3(256), 0, st, T->keys[T->sorted], T->idx[T->sorted], n, D, L,
+                       T->hkeys[0], T->hidx[0]);
+    int cur = 0;
+    for (int shift = 0; shift < 3 * L; shift += 8) {
+        hipLaunchKernelGGL(k_rs_hist<uint32_t>, dim3(T->rs_nb), dim3(RS_THREADS), 0, st, T->hkeys[cur], n, shift, T->rs_counts, T->rs_nb);
+        hipLaunchKernelGGL(k_rowscan, dim3(256), dim3(256), 0, st, T->rs_counts, T->rs_nb, T->row_total);
+        hipLaunchKernelGGL(k_rs_scatter<uint32_t>, dim3(T->rs_nb), dim3(RS_THREADS), 0, st, T->hkeys[cur], T->hidx[cur],
+                           T->hkeys[cur ^ 1], T->hidx[cur ^ 1], n, shift, T->rs_counts, T->row_total, T->rs_nb);
+        cur ^= 1;
+    }
+    NB_HIP(ctx, hipGetLastError());
+    T->horder = T->hidx[cur];
+    T->horder_age = 0;
+    T->perm_nblk = 0;  // the wavefronts' costs belonged to the previous grouping
+    return NBODY_OK;
+}
+
+void nb_tree_forget_order(nbody_ctx* ctx) {
+    if (ctx->tree) ctx->tree->horder = nullptr;
+}
+
 int nb_tree_walk(nbody_ctx* ctx, const float4* posm_in, const float4* vel_in, float4* acc_out) {
     Octree* T = ctx->tree;
     if (!T->have_tree) return nb_fail(ctx, NBODY_ERR_STATE, "no octree: call nbody_build_octree or nbody_upload_octree first");
@@ -1301,8 +1555,19 @@ int nb_tree_walk(nbody_ctx* ctx, const float4* posm_in, const float4* vel_in, fl
     const uint32_t m = (uint32_t)ctx->i_count;
     const uint32_t* order = nullptr;
     if (T->built) {
-        if (ctx->i_count == ctx->n) {
+        if (ctx->i_count == ctx->n && T->user_order) {
+            return walk_launch(ctx, T, T->user_order, (uint32_t)T->user_m, posm_in, vel_in, acc_out, 0u, 0);
+        } else if (ctx->i_count == ctx->n) {
+            // all bodies: grouped along the Hilbert curve, the order kept over several builds
+            static const bool hilbert = env_int_or("NBODY_WALK_HILBERT", 1) != 0;
             order = T->idx[T->sorted];
+            if (hilbert && T->n >= HILBERT_MIN_N) {
+                if (!T->horder || T->horder_age >= HILBERT_KEEP) {
+                    int r = make_hilbert_order(ctx, T);
+                    if (r) return r;
+                }
+                order = T->horder;
+            }
         } else {
             const uint32_t nb = ((uint32_t)T->n + CO_TILE - 1) / CO_TILE;
             const uint32_t b0 = (uint32_t)ctx->i_begin, b1 = (uint32_t)(ctx->i_begin + ctx->i_count);
@@ -1375,7 +1640,7 @@ int nb_tree_device_nodes(nbody_ctx* ctx, void** ptr, size_t* bytes) {
     const uint32_t cnt = (uint32_t)T->n_nodes;
     if (!T->export_is_upload) {  // an uploaded tree is kept as it came (renumbered); a built one is exported
         hipLaunchKernelGGL(k_export, dim3((cnt + 255) / 256), dim3(256), 0, ctx->stream, T->nodes, T->bmin, T->bmax,
-                           T->range, T->node_head, T->keys[T->sorted], T->lvl_start, (int)T->D, cnt, T->octree_rs ? 1 : 0,
+                           T->aux, T->node_head, T->keys[T->sorted], T->lvl_start, (int)T->D, cnt, T->octree_rs ? 1 : 0,
                            T->export_buf);
         NB_HIP(ctx, hipGetLastError());
     }
@@ -1446,7 +1711,8 @@ int nb_tree_upload(nbody_ctx* ctx, const nbody_octree_node* host_nodes, uint64_t
     NB_HIP(ctx, hipMemcpyAsync(T->export_buf, renum.data(), kept * sizeof(nbody_octree_node), hipMemcpyHostToDevice, ctx->stream));
     const uint32_t cnt = (uint32_t)kept;
     hipLaunchKernelGGL(k_import, dim3((cnt + 255) / 256), dim3(256), 0, ctx->stream, T->export_buf, cnt, T->nodes, T->bmin,
-                       T->bmax, T->range, mac_scale(ctx), T->err_flag);
+                       T->bmax, T->aux, mac_scale(ctx), T->err_flag);
+    hipLaunchKernelGGL(k_rope_resolve, dim3((cnt + 255) / 256), dim3(256), 0, ctx->stream, T->aux, cnt);
     NB_HIP(ctx, hipGetLastError());
     NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     T->n_nodes = kept;
@@ -1455,6 +1721,33 @@ int nb_tree_upload(nbody_ctx* ctx, const nbody_octree_node* host_nodes, uint64_t
     T->export_is_upload = true;
     ctx->counters.octree_nodes = kept;
     return check_err_flag(ctx, T, "nbody_upload_octree");
+}
+
+// The grouping of the traversal's targets into wavefronts (64 consecutive entries each): body
+// indices, every body exactly once, NO_NODE for a lane left empty.  Null: back to the sorted order.
+int nb_tree_set_target_order(nbody_ctx* ctx, const uint32_t* host_order, uint64_t count) {
+    Octree* T = ctx->tree;
+    if (T->user_order) NB_HIP(ctx, hipFree(T->user_order));
+    T->user_order = nullptr;
+    T->user_m = 0;
+    T->perm_nblk = 0;
+    if (!host_order) return NBODY_OK;
+    if (count < T->n || count > 4 * T->n + 64) return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_bh_set_target_order: count must be in [n_bodies, 4 n_bodies + 64]");
+    std::vector<uint8_t> seen(T->n, 0);
+    uint64_t bodies = 0;
+    for (uint64_t r = 0; r < count; ++r) {
+        const uint32_t b = host_order[r];
+        if (b == NO_NODE) continue;
+        if (b >= T->n || seen[b]) return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_bh_set_target_order: not a permutation of the body indices");
+        seen[b] = 1;
+        ++bodies;
+    }
+    if (bodies != T->n) return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_bh_set_target_order: every body must appear once");
+    NB_HIP(ctx, hipMalloc(&T->user_order, count * sizeof(uint32_t)));
+    NB_HIP(ctx, hipMemcpyAsync(T->user_order, host_order, count * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    T->user_m = count;
+    return NBODY_OK;
 }
 
 int nb_tree_keys(nbody_ctx* ctx, uint64_t* keys, uint8_t* depth, uint32_t* order) {

@@ -218,6 +218,15 @@ class NBodySim:
         self._ck(self.lib.nbody_morton_keys(self.h, _ptr(keys), _ptr(depth), _ptr(order)))
         return keys, depth, order
 
+    def bh_set_target_order(self, order):
+        """Grouping of the traversal's targets into wavefronts (64 consecutive entries each): body indices,
+        0xffffffff = empty lane; None restores the library's own order.  Results do not depend on it."""
+        if order is None:
+            self._ck(self.lib.nbody_bh_set_target_order(self.h, None, 0))
+            return
+        order = np.ascontiguousarray(order, dtype=np.uint32)
+        self._ck(self.lib.nbody_bh_set_target_order(self.h, _ptr(order), len(order)))
+
     # -- measurement ---------------------------------------------------------------------------
     def energy(self):
         k, u = C.c_double(), C.c_double()

@@ -589,8 +589,10 @@ int orc_bh_accel(int law, int64_t n, const float* pos16, const float* vel16, con
 
 // The same traversal (identical f32 acceptance decisions, so the identical node sequence) with
 // every accepted term evaluated and summed in f64: the yardstick for the walk's rounding error.
+// abs_out (optional, one double per body): the sum of the accepted terms' magnitudes, the scale of the
+// rounding error ANY f32 summation order of those terms carries.
 void orc_bh_accel_f64(int law, int64_t n, const float* pos16, const float* vel16, const Node96* nodes, double G,
-                      double eps2, float theta, int64_t i_begin, int64_t i_count, double* acc_out) {
+                      double eps2, float theta, int64_t i_begin, int64_t i_count, double* acc_out, double* abs_out) {
     (void)n;
 #pragma omp parallel for schedule(dynamic, 256)
     for (int64_t i = i_begin; i < i_begin + i_count; ++i) {
@@ -603,6 +605,7 @@ void orc_bh_accel_f64(int law, int64_t n, const float* pos16, const float* vel16
             v[2] = vel16[4 * i + 2];
         }
         double a[3] = {0, 0, 0};
+        double mag = 0;
         std::vector<uint32_t> stack;
         stack.push_back(0);
         while (!stack.empty()) {
@@ -622,6 +625,7 @@ void orc_bh_accel_f64(int law, int64_t n, const float* pos16, const float* vel16
                 a[0] += t[0];
                 a[1] += t[1];
                 a[2] += t[2];
+                mag += std::sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
             } else if (node.node_type == T_LEAFLIST) {
                 uint32_t j = node.child[0], k = 0;
                 do {
@@ -636,6 +640,7 @@ void orc_bh_accel_f64(int law, int64_t n, const float* pos16, const float* vel16
         acc_out[3 * (i - i_begin)] = a[0];
         acc_out[3 * (i - i_begin) + 1] = a[1];
         acc_out[3 * (i - i_begin) + 2] = a[2];
+        if (abs_out) abs_out[i - i_begin] = mag;
     }
 }
 

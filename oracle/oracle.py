@@ -151,16 +151,18 @@ def bh_accel(law, pos16, vel16, nodes, G=0.0066743, eps2=1.0, theta=0.5, i_begin
     return out, dict(visits=int(cnt[0]), leaf=int(cnt[1]), aggregate=int(cnt[2]), max_stack=int(cnt[3]))
 
 
-def bh_accel_f64(law, pos16, vel16, nodes, G=0.0066743, eps2=1.0, theta=0.5, i_begin=0, i_count=None):
-    """The same node sequence as bh_accel, terms evaluated and summed in float64."""
+def bh_accel_f64(law, pos16, vel16, nodes, G=0.0066743, eps2=1.0, theta=0.5, i_begin=0, i_count=None, with_abs=False):
+    """The same node sequence as bh_accel, terms evaluated and summed in float64.  with_abs: also the sum
+    of the terms' magnitudes per body (the scale of any f32 summation order's rounding error)."""
     pos16, vel16 = _c(pos16), _c(vel16)
     nodes = np.ascontiguousarray(nodes)
     n = len(pos16)
     i_count = n - i_begin if i_count is None else i_count
     out = np.zeros((i_count, 3), np.float64)
+    mag = np.zeros(i_count, np.float64) if with_abs else None
     lib().orc_bh_accel_f64(C.c_int(law), C.c_int64(n), _p(pos16), _p(vel16), _p(nodes), C.c_double(float(np.float32(G))),
-                           C.c_double(eps2), C.c_float(theta), C.c_int64(i_begin), C.c_int64(i_count), _p(out))
-    return out
+                           C.c_double(eps2), C.c_float(theta), C.c_int64(i_begin), C.c_int64(i_count), _p(out), _p(mag))
+    return (out, mag) if with_abs else out
 
 
 def step_bh(law, masses, pos, vel, acc, nsteps, G=0.0066743, eps2=1.0, dt=0.1, theta=0.5, world=250.0, max_depth=16,

@@ -113,6 +113,7 @@ extern "C" {
     /// No counterpart in the reference: RCCL communicator inside the library (one process per GPU).
     pub fn nbody_comm_unique_id(id_out128: *mut c_void) -> c_int;
     pub fn nbody_comm_init(ctx: *mut nbody_ctx, unique_id128: *const c_void, rank: c_int, world: c_int) -> c_int;
+    pub fn nbody_bh_set_target_order(ctx: *mut nbody_ctx, host_order: *const u32, count: u64) -> c_int;
     pub fn nbody_comm_sorted_run(n_bodies: u64, world: c_int, rank: c_int, begin: *mut u64, count: *mut u64) -> c_int;
     pub fn nbody_comm_exchange_plan(n_bodies: u64, world: c_int, begin: *const u64, count: *const u64) -> c_int;
     pub fn nbody_accel_allpairs(ctx: *mut nbody_ctx, host_acc16_out: *mut f32) -> c_int;

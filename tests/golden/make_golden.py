@@ -39,10 +39,11 @@ def main():
             d["keys"] = orc.morton_keys(pos)
             for name, law in (("wgsl_bias", 1), ("plummer", 2)):
                 d[f"bh_acc_{name}"], _ = orc.bh_accel(law, pos, vel, nodes)
+            # src/nbody_cpu.rs: 100 steps (N = 4,096 is the reference's CPU configuration at its own size),
+            # both buffer sets started from the same positions
+            r = orc.step_cpu(m, pos, z, z, pos, z, z, 100)
+            d["cpu100_pos"], d["cpu100_vel"] = r[0], r[1]
             if n <= 250:
-                # src/nbody_cpu.rs: 100 steps, both buffer sets started from the same positions
-                r = orc.step_cpu(m, pos, z, z, pos, z, z, 100)
-                d["cpu100_pos"], d["cpu100_vel"] = r[0], r[1]
                 p, v, a = orc.step_wgsl_allpairs(1, m, pos, vel, z, 20)
                 d["wgsl20_pos"], d["wgsl20_vel"], d["wgsl20_acc"] = p, v, a
                 p, v, a = orc.step_bh(1, m, pos, vel, z, 10)

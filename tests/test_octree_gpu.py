@@ -19,13 +19,16 @@ def check_walk(orc, law, pos, vel, nodes, acc_gpu, what):
     """1e-5 relative per body.  The f32 reference walk is itself only known to its own rounding
     error e_ref against the float64 evaluation of the same node sequence (large for
     cancellation-dominated bodies), so the bound on the distance to float64 is 1e-5*|a| + e_ref:
-    everything within 1e-5 of the reference satisfies it, by the triangle inequality."""
+    everything within 1e-5 of the reference satisfies it, by the triangle inequality.  The GPU adds
+    the same terms in another order (a node's children together; subtrees that few lanes open,
+    last), whose own f32 rounding is priced as in the all-pairs tests: 4 eps x the sum of the terms'
+    magnitudes."""
     ref32, _ = orc.bh_accel(law, pos, vel, nodes)
-    ref64 = orc.bh_accel_f64(law, pos, vel, nodes)
+    ref64, mag = orc.bh_accel_f64(law, pos, vel, nodes, with_abs=True)
     e_gpu = np.linalg.norm(acc_gpu[:, :3].astype(np.float64) - ref64, axis=1)
     e_ref = np.linalg.norm(ref32[:, :3].astype(np.float64) - ref64, axis=1)
     scale = np.linalg.norm(ref64, axis=1)
-    bad = e_gpu > TOL * scale + e_ref + 1e-30
+    bad = e_gpu > TOL * scale + e_ref + 4 * np.finfo(np.float32).eps * mag + 1e-30
     assert not bad.any(), f"{what}: {bad.sum()} bodies off, worst {np.max(e_gpu / scale):.3e}"
     assert np.quantile(body_rel_err(acc_gpu, ref32), 0.99) < TOL, what
 

@@ -100,3 +100,45 @@ def test_exchange_buffer_is_not_touched_by_transfers_and_stale_forces_are_refuse
         assert e.value.code == -4
         sim.bh_forces_ranked(0, 5000)
         sim.integrate_ranked()
+
+
+@pytest.mark.parametrize("law", [nb.LAW_PLUMMER, nb.LAW_WGSL_BIAS])
+def test_a_nan_position_ends_in_nan_accelerations_not_in_an_endless_traversal(orc, law):
+    """A body with a NaN coordinate makes every distance to its cells NaN: no cell is accepted, all are
+    opened down to the body's own leaf, whose term is NaN -- for every target, as in the reference's
+    traversal (src/nbodybh.wgsl:76-102 interacts with a LEAFBODY whatever the distance).  The
+    traversal must end (a leaf record is never opened, an empty group never pushed) and agree with
+    the oracle's on the same tree bytes about which results are NaN."""
+    n = 3000
+    m, p = nb.gen_refcube(n, seed=4)
+    p[1234, 1] = np.nan
+    v = np.zeros((n, 4), np.float32)
+    with nb.NBodySim(n, law=law) as sim:
+        sim.upload(m, p, v)
+        sim.build_octree()
+        nodes = sim.download_octree()
+        sim.set_counting(True)
+        acc = sim.accel_bh()
+        c = sim.counters()
+        sim.step_bh(2)          # and a step on top of it returns as well
+        sim.sync()
+    ref, rc = orc.bh_accel(law, p, v, np.ascontiguousarray(nodes.view(orc.NODE_DTYPE)))
+    assert np.array_equal(np.isnan(acc[:, :3]), np.isnan(ref[:, :3]))
+    assert np.isnan(acc[:, :3]).any()
+    assert c["bh_node_visits"] == rc["visits"]
+
+
+def test_an_uploaded_interior_node_without_children_is_refused(orc):
+    n = 500
+    m, p = nb.gen_refcube(n, seed=6)
+    nodes, _, _, _ = orc.build_octree(p, m)
+    bad = nodes.copy()
+    k = int(np.flatnonzero(bad["node_type"] == nb.NODE_INTERIOR)[-1])
+    bad["child"][k, :] = 0
+    with nb.NBodySim(n, law=nb.LAW_PLUMMER) as sim:
+        sim.upload(m, p)
+        with pytest.raises(nb.NBodyError) as e:
+            sim.upload_octree(bad.view(nb.NODE_DTYPE))
+        assert e.value.code == -1 and "no children" in str(e.value)
+        sim.upload_octree(nodes.view(nb.NODE_DTYPE))   # the intact tree still goes in
+        assert np.isfinite(sim.accel_bh()).all()

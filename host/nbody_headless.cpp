@@ -12,6 +12,8 @@
 // --dump FILE writes what the reference's renderer binds (src/trace.wgsl:23-27): a 16-byte header
 // {"NBF1", u32 n, u32 frames written, u32 0}, masses f32[n], then per reported frame the positions
 // as f32[n][4] (vec3 stride 16, pad lane 0), so that a viewer can replay the run.
+// --state FILE writes the final state for comparisons between runs: {"NBS1", u32 n, u32 0, u32 0}, then
+// positions, velocities and accelerations, each f32[n][4].
 // --ranks R runs R processes, one per GPU (device = rank mod --devices, default R), that exchange
 // inside the library (nbody_comm_init): the all-pairs modes split the targets into R index ranges,
 // the Barnes-Hut mode keeps all bodies on every rank and splits the traversal.  Rank 0 makes the
@@ -35,7 +37,7 @@ namespace {
 struct Options {
     int ranks = 1, devices = 0;
     bool force_comm = false;
-    std::string mode = "gpu", law, dataset = "refcube", dump;
+    std::string mode = "gpu", law, dataset = "refcube", dump, state;
     uint64_t n = 250;  // N_BODIES, src/nbody_gpu.rs:14
     int frames = 100, report = 50;
     uint64_t seed = 42;
@@ -137,6 +139,18 @@ int run_rank(const Options& o, int rank, const std::string& id_path) {
         std::fwrite(&dumped, sizeof dumped, 1, out);
         std::fclose(out);
     }
+    if (rank == 0 && !o.state.empty()) {
+        std::vector<float> vel(4 * n), acc(4 * n);
+        if ((rc = nbody_download(ctx, pos.data(), vel.data(), acc.data()))) return die(ctx, "nbody_download", rc);
+        std::FILE* f = std::fopen(o.state.c_str(), "wb");
+        if (!f) { std::fprintf(stderr, "cannot open %s\n", o.state.c_str()); nbody_destroy(ctx); return 1; }
+        const uint32_t head[4] = {0x3153424eu /* "NBS1" */, (uint32_t)n, 0u, 0u};
+        std::fwrite(head, sizeof head, 1, f);
+        std::fwrite(pos.data(), sizeof(float), 4 * n, f);
+        std::fwrite(vel.data(), sizeof(float), 4 * n, f);
+        std::fwrite(acc.data(), sizeof(float), 4 * n, f);
+        std::fclose(f);
+    }
     nbody_destroy(ctx);
     return 0;
 }
@@ -156,13 +170,14 @@ int main(int argc, char** argv) {
         else if (a == "--report") o.report = std::atoi(next());
         else if (a == "--seed") o.seed = std::strtoull(next(), nullptr, 10);
         else if (a == "--dump") o.dump = next();
+        else if (a == "--state") o.state = next();
         else if (a == "--ranks") o.ranks = std::atoi(next());
         else if (a == "--devices") o.devices = std::atoi(next());
         else if (a == "--comm") o.force_comm = true;  // a communicator even with one rank
         else {
             std::fprintf(stderr,
                          "usage: %s [--mode cpu|gpu|bh] [--law cpu_r6|wgsl_bias|plummer] [--dataset refcube|plummer] [--n N] "
-                         "[--frames F] [--report R] [--seed S] [--dump FILE] [--ranks R] [--devices D] [--comm]\n",
+                         "[--frames F] [--report R] [--seed S] [--dump FILE] [--state FILE] [--ranks R] [--devices D] [--comm]\n",
                          argv[0]);
             return 2;
         }

@@ -38,8 +38,6 @@ namespace {
 constexpr int NCNT = 18;       // level counters 0..16 + leaf-list members
 constexpr int LIST_ROW = 17;
 constexpr uint32_t NO_NODE = 0xffffffffu;
-constexpr uint32_t ROPE_FLAG = 0x80000000u;
-constexpr uint32_t ROPE_END = 0x7fffffffu;
 constexpr int NWALK_COUNTERS = 24;  // 8 totals + 16 bins of wavefront visits by active lanes
 
 // Node record (32 B): written by the build, fetched by the traversal with scalar loads.
@@ -81,16 +79,6 @@ __device__ __forceinline__ void qn_set_range(QNode& nd, float range, MacScale ma
 }
 static_assert(sizeof(QNode) == 32, "node record layout");
 
-// Per node, beside its record: what the traversal needs only now and then.  `range` is the longest
-// side of the node's bounding box (src/octree_maxdepth.rs:101; read where a distance falls between
-// the two thresholds); `rope` is the node that the reference's depth-first order reaches next when
-// this node's subtree is skipped (its next sibling, else its parent's rope), ROPE_END after the
-// last node.  While the ropes are being made, ROPE_FLAG | parent stands for "the parent's rope"
-// (node ids stay below 2^31).
-struct NodeAux {
-    float range;
-    uint32_t rope;
-};
 
 }  // namespace
 
@@ -118,7 +106,7 @@ struct Octree {
     QNode* nodes = nullptr;
     float4* bmin = nullptr;          // bounding box of the bodies below each node
     float4* bmax = nullptr;
-    NodeAux* aux = nullptr;          // longest side of that box (src/octree_maxdepth.rs:101), and the node's rope
+    float* range = nullptr;          // longest side of that box (src/octree_maxdepth.rs:101)
     uint32_t* node_head = nullptr;   // sorted rank of the first body of each node's cell
     float* quad = nullptr;           // opt-in: traceless quadrupole about the node's centre of mass,
                                      // 8 floats per node {xx, xy, xz, yy, yz, zz, 0, 0}
@@ -490,7 +478,7 @@ __global__ __launch_bounds__(256) void k_emit(const uint64_t* __restrict__ keys,
                                               const uint8_t* __restrict__ lo, const uint8_t* __restrict__ top,
                                               const uint8_t* __restrict__ flags, const uint32_t* __restrict__ blk,
                                               uint32_t nb, const uint32_t* __restrict__ lvl_start, QNode* __restrict__ nodes,
-                                              float4* __restrict__ bmin, float4* __restrict__ bmax, NodeAux* __restrict__ aux,
+                                              float4* __restrict__ bmin, float4* __restrict__ bmax, float* __restrict__ range,
                                               uint32_t* __restrict__ node_head, uint32_t* __restrict__ body_node,
                                               uint32_t cap_nodes, uint32_t* __restrict__ err_flag) {
     __shared__ uint32_t wtot[NCNT][4];
@@ -566,7 +554,7 @@ __global__ __launch_bounds__(256) void k_emit(const uint64_t* __restrict__ keys,
 __global__ void k_leaflist(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idx,
                            const float4* __restrict__ posm, uint32_t n, int list_mode, const uint8_t* __restrict__ flags,
                            const uint32_t* __restrict__ body_node, QNode* __restrict__ nodes, float4* __restrict__ bmin,
-                           float4* __restrict__ bmax, NodeAux* __restrict__ aux, uint32_t* __restrict__ node_head,
+                           float4* __restrict__ bmax, float* __restrict__ range, uint32_t* __restrict__ node_head,
                            uint32_t cap_nodes, MacScale mac) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || !(flags[i] & 2u)) return;
@@ -587,7 +575,6 @@ __global__ void k_leaflist(const uint64_t* __restrict__ keys, const uint32_t* __
             c.count_type = qn_pack(0, NBODY_NODE_LEAFBODY);
             nodes[member] = c;
             node_head[member] = i;
-            aux[member].rope = member + 1;  // the next member; the last one is redirected below
         }
         ++member;
         ++count;
@@ -609,9 +596,8 @@ __global__ void k_leaflist(const uint64_t* __restrict__ keys, const uint32_t* __
     const float rg = fmaxf(mxx - mnx, fmaxf(mxy - mny, mxz - mnz));
     qn_set_range(nd, rg, mac);
     nd.count_type = qn_pack(count, NBODY_NODE_LEAFLIST);
-    if (count && member - 1 < cap_nodes) aux[member - 1].rope = ROPE_FLAG | id;  // after the last member: wherever the cell's rope leads
     nodes[id] = nd;
-    aux[id].range = rg;
+    range[id] = rg;
     bmin[id] = make_float4(mnx, mny, mnz, 0.0f);
     bmax[id] = make_float4(mxx, mxy, mxz, 0.0f);
 }
@@ -620,19 +606,13 @@ __global__ void k_leaflist(const uint64_t* __restrict__ keys, const uint32_t* __
 // One level: nodes [first_id, first_id + count).  The children of a node end where the next
 // node's begin (`child_end` for the last node of the level).
 __global__ void k_aggregate(QNode* __restrict__ nodes, float4* __restrict__ bmin, float4* __restrict__ bmax,
-                            NodeAux* __restrict__ aux, uint32_t first_id, uint32_t count, uint32_t child_end, MacScale mac) {
+                            float* __restrict__ range, uint32_t first_id, uint32_t count, uint32_t child_end, MacScale mac) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= count) return;
     const uint32_t id = first_id + r;
-    if (id == 0) aux[0].rope = ROPE_END;  // nothing follows the root
     QNode nd = nodes[id];
     if (qn_type(nd) != NBODY_NODE_INTERIOR) return;
     const uint32_t c0 = nd.first, c1 = (r + 1 < count) ? nodes[id + 1].first : child_end;
-    // ropes of the children: the next sibling; after the last child, wherever this node's rope leads
-    // (resolved by k_rope_resolve once every level has written its links)
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-        if (c0 + k < c1) aux[c0 + k].rope = (c0 + k + 1 < c1) ? c0 + k + 1 : (ROPE_FLAG | id);
     // An interior node has at most eight children: all their records (and the boxes of those that
     // are cells themselves) are requested before the first is used; the sums then run in child
     // order, as a loop over the children would.
@@ -672,25 +652,9 @@ __global__ void k_aggregate(QNode* __restrict__ nodes, float4* __restrict__ bmin
     qn_set_range(nd, rg, mac);
     nd.count_type = qn_pack(c1 - c0, NBODY_NODE_INTERIOR);
     nodes[id] = nd;
-    aux[id].range = rg;
+    range[id] = rg;
     bmin[id] = make_float4(mnx, mny, mnz, 0.0f);
     bmax[id] = make_float4(mxx, mxy, mxz, 0.0f);
-}
-
-// Replaces every "my parent's rope" link by the node it stands for.  A thread follows the chain
-// of last children upward until it meets a resolved rope; links that other threads resolve in the
-// meantime are read either way (old: one more hop, new: the answer), with the same result.
-__global__ void k_rope_resolve(NodeAux* aux, uint32_t count) {
-    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= count) return;
-    uint32_t r = aux[id].rope;
-    if (!(r & ROPE_FLAG)) return;
-    for (int hop = 0; hop < 64 && (r & ROPE_FLAG); ++hop) {
-        const uint32_t up = r & ~ROPE_FLAG;
-        if (up >= count) break;  // (never: a link names an existing node)
-        r = aux[up].rope;
-    }
-    aux[id].rope = (r & ROPE_FLAG) ? ROPE_END : r;  // (a chain longer than any tree has levels: end the traversal there)
 }
 
 // ---- 7b. quadrupole moments (opt-in, no counterpart in the reference) -----------------------
@@ -733,7 +697,7 @@ __global__ void k_quadrupole(const QNode* __restrict__ nodes, float* __restrict_
 
 // ---- export / import (96-byte reference layout) ---------------------------------------------
 __global__ void k_export(const QNode* __restrict__ nodes, const float4* __restrict__ bmin, const float4* __restrict__ bmax,
-                         const NodeAux* __restrict__ aux, const uint32_t* __restrict__ node_head, const uint64_t* __restrict__ keys,
+                         const float* __restrict__ range, const uint32_t* __restrict__ node_head, const uint64_t* __restrict__ keys,
                          const uint32_t* __restrict__ lvl_start, int D, uint32_t count, int octree_rs,
                          nbody_octree_node* __restrict__ out) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
@@ -748,7 +712,7 @@ __global__ void k_export(const QNode* __restrict__ nodes, const float4* __restri
     o.center_of_mass[0] = nd.cx; o.center_of_mass[1] = nd.cy; o.center_of_mass[2] = nd.cz; o._pad0 = 0.0f;
     o.pos_min[0] = lo.x; o.pos_min[1] = lo.y; o.pos_min[2] = lo.z; o._pad1 = 0.0f;
     o.pos_max[0] = hi.x; o.pos_max[1] = hi.y; o.pos_max[2] = hi.z;
-    o.range = leaf ? 0.0f : aux[id].range;
+    o.range = leaf ? 0.0f : range[id];
     o.total_mass = nd.mass;
     for (int k = 0; k < 8; ++k) o.child_indices[k] = 0;
     const uint32_t type = qn_type(nd), cnt = qn_count(nd);
@@ -780,11 +744,10 @@ __global__ void k_export(const QNode* __restrict__ nodes, const float4* __restri
 
 // Uploaded trees arrive renumbered breadth-first by the host: children consecutive in octant order.
 __global__ void k_import(const nbody_octree_node* __restrict__ in, uint32_t count, QNode* __restrict__ nodes,
-                         float4* __restrict__ bmin, float4* __restrict__ bmax, NodeAux* __restrict__ aux, MacScale mac,
+                         float4* __restrict__ bmin, float4* __restrict__ bmax, float* __restrict__ range, MacScale mac,
                          uint32_t* __restrict__ err_flag) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= count) return;
-    if (id == 0) aux[0].rope = ROPE_END;
     const nbody_octree_node o = in[id];
     QNode nd;
     nd.cx = o.center_of_mass[0]; nd.cy = o.center_of_mass[1]; nd.cz = o.center_of_mass[2];
@@ -808,11 +771,8 @@ __global__ void k_import(const nbody_octree_node* __restrict__ in, uint32_t coun
         cnt = max(o.child_indices[1], 1u);  // src/nbodybh.wgsl:139-146 is a do-while: at least one member
     }
     nd.count_type = qn_pack(cnt, o.node_type);
-    // ropes of the children / members (consecutive after the host's renumbering)
-    for (uint32_t c = 0; c < cnt && nd.first + c < count; ++c)
-        aux[nd.first + c].rope = (c + 1 < cnt) ? nd.first + c + 1 : (ROPE_FLAG | id);
     nodes[id] = nd;
-    aux[id].range = o.range;
+    range[id] = o.range;
     bmin[id] = make_float4(o.pos_min[0], o.pos_min[1], o.pos_min[2], 0.0f);
     bmax[id] = make_float4(o.pos_max[0], o.pos_max[1], o.pos_max[2], 0.0f);
 }
@@ -883,12 +843,6 @@ constexpr int WALK_BATCH = 8;    // node records fetched together; the node arra
 constexpr int HILBERT_LEVELS = 10;      // levels of the octree the Hilbert keys resolve (30 bits, four sort passes)
 constexpr uint32_t HILBERT_KEEP = 16;   // builds after which the order is made afresh
 constexpr uint64_t HILBERT_MIN_N = 32768;  // below this the sort costs more than the grouping saves
-constexpr int DEFER_SLOTS = 12;  // nodes a lane can note for its own second-phase walk (LDS: 4 B x 64 lanes each)
-#ifndef NBODY_WALK_DEFER_LANES
-#define NBODY_WALK_DEFER_LANES 12
-#endif
-constexpr int WALK_DEFER_LANES = NBODY_WALK_DEFER_LANES;  // a node opened by at most this many lanes is left to their own walks (0: never)
-
 
 // The lanes for which p holds, as a wave-uniform value the compiler keeps in scalar registers
 // (without the empty asm it folds "ballot != 0" back into a per-lane test).
@@ -920,21 +874,16 @@ __device__ __forceinline__ void pin_moment(const QMoment& m) {
 // remainder on the stack.
 // Seven wavefronts per SIMD (at most 96 scalar registers): measured 4 % faster at N = 16M than the
 // six the unconstrained allocation is admitted with; eight (80) spills and is twice as slow.
-template <int LAW, bool COUNT, bool QUAD, int DEFER_LANES>
+template <int LAW, bool COUNT, bool QUAD>
 __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_walk(const QNode* __restrict__ q, const uint32_t* __restrict__ order, uint32_t m,
                                               uint32_t i_begin, const float4* __restrict__ posm,
                                               const float4* __restrict__ vel, float4* __restrict__ acc_out, float G,
-                                              float eps2, float theta, const NodeAux* __restrict__ aux,
+                                              float eps2, float theta, const float* __restrict__ range,
                                               unsigned long long* __restrict__ counters,
                                               uint32_t* __restrict__ err_flag, int out_by_rank,
                                               const float* __restrict__ quad, const uint32_t* __restrict__ perm,
-                                              uint32_t* __restrict__ wave_cost, uint32_t n_nodes) {
+                                              uint32_t* __restrict__ wave_cost) {
     __shared__ uint4 stack[WALK_STACK];  // {first, count, mask.lo, mask.hi}
-    // Nodes that only a few lanes open are not walked by the whole wavefront: each of those lanes
-    // notes the node here and walks its subtree by itself afterwards (second phase below).
-    __shared__ uint32_t dlist[DEFER_SLOTS][WALK_THREADS];
-    constexpr bool DEFER = !QUAD && DEFER_LANES > 0;
-    uint32_t n_def = 0;
     const int lane = threadIdx.x;
     // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2): give each XCD one
     // contiguous eighth of the Morton order, so that it keeps meeting the same part of the tree.
@@ -1064,23 +1013,11 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(7,
                     unsigned long long open = rest;
                     const unsigned long long unsure = rest & lanes(!(r2 < nd.r2_open));
                     if (unsure) {
-                        const float rg = aux[first + k].range;
+                        const float rg = range[first + k];
                         const float rr = sqrtf(((dx * dx) + (dy * dy)) + (dz * dz));  // distance(pos, com)
                         open &= ~(unsure & lanes((rg / rr) < theta));
                     }
-                    bool deferred = false;
-                    if (DEFER && open && qn_type(nd) == NBODY_NODE_INTERIOR && (uint32_t)__popcll(open) <= (uint32_t)DEFER_LANES) {
-                        // few lanes open it: each takes the subtree for itself, if all of them have room to note it
-                        const bool mine = __builtin_amdgcn_inverse_ballot_w64(open);
-                        if (lanes(mine && n_def >= (uint32_t)DEFER_SLOTS) == 0) {
-                            if (mine) {
-                                dlist[n_def][lane] = first + k;
-                                ++n_def;
-                            }
-                            deferred = true;
-                        }
-                    }
-                    if (open && qn_count(nd) && !deferred) {  // (an empty group is never pushed: a popped group has >= 1 record)
+                    if (open && qn_count(nd)) {  // (an empty group is never pushed: a popped group has >= 1 record)
                         // INTERIOR: its children; LEAFLIST: its members (LEAFBODY records, src/nbodybh.wgsl:137-146)
                         if (top_v < WALK_STACK) {
                             stack[top_v] = make_uint4(nd.first, qn_count(nd), (uint32_t)open, (uint32_t)(open >> 32));
@@ -1122,70 +1059,6 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(7,
         }
         top = __builtin_amdgcn_readlane(top_v, (int)__builtin_ctzll(mask));
         if (COUNT) max_top = max(max_top, (uint32_t)top);  // pushes only grow the stack within a batch
-    }
-    if (DEFER) {
-        // Second phase: every lane walks the subtrees it noted, by itself -- one record per step, its own
-        // record (vector loads), no stack: where a node is taken or skipped the walk goes on at rope[node],
-        // where it is opened at its first child; a noted node's subtree ends where that node's own rope
-        // leads.  The decisions are those of the first phase (src/nbodybh.wgsl:76-134), so a lane still
-        // meets exactly the nodes of the reference's traversal; only the order of its sum changes.
-        uint32_t cur = ROPE_END, end = ROPE_END;
-        uint32_t steps = 0;
-        for (;;) {
-            if (cur == end && n_def > 0) {
-                --n_def;
-                const uint32_t p = dlist[n_def][lane];  // (a node this lane noted itself: always a valid index)
-                cur = q[p].first;
-                end = aux[p].rope;
-            }
-            bool active = cur != end;
-            if (active && cur >= n_nodes) {  // (never, with the links the build makes: a broken link ends the lane's walk)
-                *err_flag = 4;
-                cur = end;
-                active = false;
-            }
-            const unsigned long long act = lanes(active);
-            if (act == 0) break;
-            if (++steps > n_nodes) {  // (a lane meets a node at most once: more steps than nodes means links in a circle)
-                *err_flag = 4;
-                break;
-            }
-            n_wave += 1;
-            if (COUNT && lane == 0) atomicAdd(&counters[8 + ((int)__popcll(act) - 1) / 4], 1ull);
-            if (active) {
-                const QNode nd = q[cur];
-                const NodeAux na = aux[cur];
-                const uint32_t next = na.rope;
-                if (COUNT) ++n_visit;
-                const float dx = nd.cx - t.x, dy = nd.cy - t.y, dz = nd.cz - t.z;
-                const float r2 = LAW == NBODY_LAW_PLUMMER ? fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, eps2)))
-                                                          : fmaf(dx, dx, fmaf(dy, dy, dz * dz));
-                bool open = false;
-                if (!(r2 > nd.r2_accept) && qn_type(nd) != NBODY_NODE_LEAFBODY) {
-                    open = r2 < nd.r2_open;
-                    if (!open) {  // between the thresholds: the reference's own expression
-                        const float rr = sqrtf(((dx * dx) + (dy * dy)) + (dz * dz));
-                        open = !((na.range / rr) < theta);
-                    }
-                }
-                if (COUNT && !open) {
-                    if (qn_type(nd) == NBODY_NODE_LEAFBODY) ++n_leaf;
-                    else ++n_agg;
-                }
-                float sc;
-                if (LAW == NBODY_LAW_PLUMMER) {
-                    const float ri = WALK_PRECISE ? rsq_refined(r2) : __builtin_amdgcn_rsqf(r2);
-                    sc = (nd.mass * ri) * (ri * ri);
-                } else {
-                    sc = pair_scale<LAW, WALK_PRECISE>(t, dx, dy, dz, r2, nd.mass, eps2);
-                }
-                const float w = open ? 0.0f : sc;
-                ax = fmaf(w, dx, ax);
-                ay = fmaf(w, dy, ay);
-                az = fmaf(w, dz, az);
-                cur = (open && qn_count(nd)) ? nd.first : next;
-            }
-        }
     }
     if (valid) acc_out[out_by_rank ? i_begin + r : b] = make_float4(G * ax, G * ay, G * az, 0.0f);
     if (wave_cost && lane == 0) wave_cost[blk] = n_wave;
@@ -1251,9 +1124,8 @@ MacScale mac_scale(const nbody_ctx* ctx) {
 int ensure_nodes(nbody_ctx* ctx, Octree* T, uint64_t need) {
     if (need <= T->cap_nodes) return NBODY_OK;
     uint64_t cap = std::max<uint64_t>(need + need / 4 + 1024, 2 * T->n + 1024);
-    if (need >= ROPE_END) return nb_fail(ctx, NBODY_ERR_CAPACITY, "octree needs more than 2^31 nodes");
-    cap = std::min<uint64_t>(cap, ROPE_END);
-    void** arrays[] = {(void**)&T->nodes, (void**)&T->node_head, (void**)&T->bmin, (void**)&T->bmax, (void**)&T->aux, (void**)&T->quad};
+    if (cap > 0xfffffff0ull) return nb_fail(ctx, NBODY_ERR_CAPACITY, "octree needs more than 2^32 nodes");
+    void** arrays[] = {(void**)&T->nodes, (void**)&T->node_head, (void**)&T->bmin, (void**)&T->bmax, (void**)&T->range, (void**)&T->quad};
     for (void** a : arrays) {
         if (*a) (void)hipFree(*a);
         *a = nullptr;
@@ -1262,7 +1134,7 @@ int ensure_nodes(nbody_ctx* ctx, Octree* T, uint64_t need) {
     T->have_tree = false;
     // the traversal fetches whole batches: pad so that the last group's batch stays inside
     hipError_t e = hipMalloc(&T->nodes, (cap + WALK_BATCH) * sizeof(QNode));
-    if (e == hipSuccess) e = hipMalloc(&T->aux, cap * sizeof(NodeAux));
+    if (e == hipSuccess) e = hipMalloc(&T->range, cap * sizeof(float));
     if (e == hipSuccess && ctx->cfg.quadrupole) e = hipMalloc(&T->quad, (cap + WALK_BATCH) * 8 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&T->node_head, cap * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&T->bmin, cap * sizeof(float4));
@@ -1288,7 +1160,7 @@ int check_err_flag(nbody_ctx* ctx, Octree* T, const char* what) {
         return nb_fail(ctx, NBODY_ERR_CAPACITY,
                        std::string(what) + (h == 2 ? ": traversal stack overflow"
                                             : h == 3 ? ": children of a node are not consecutive"
-                                            : h == 4 ? ": a lane's own walk did not end (broken node links)"
+
                                                      : ": node capacity exceeded"));
     }
     return NBODY_OK;
@@ -1305,9 +1177,9 @@ void launch_walk(nbody_ctx* ctx, Octree* T, const uint32_t* order, uint32_t m, c
     const uint32_t* perm = ordered && T->perm_nblk == grid.x && T->perm_order == order ? T->wave_perm : nullptr;
     uint32_t* cost = ordered ? T->wave_cost : nullptr;
 #define NB_WALK(COUNT, QUAD)                                                                                              \
-    hipLaunchKernelGGL((k_walk<LAW, COUNT, QUAD, WALK_DEFER_LANES>), grid, dim3(WALK_THREADS), 0, ctx->stream, T->nodes, order, m, i_begin, posm, \
-                       vel, acc_out, ctx->cfg.G, ctx->cfg.eps2, ctx->cfg.theta, T->aux,                                 \
-                       (unsigned long long*)T->walk_counters, T->err_flag, out_by_rank, T->quad, perm, cost, (uint32_t)T->n_nodes)
+    hipLaunchKernelGGL((k_walk<LAW, COUNT, QUAD>), grid, dim3(WALK_THREADS), 0, ctx->stream, T->nodes, order, m, i_begin, posm, \
+                       vel, acc_out, ctx->cfg.G, ctx->cfg.eps2, ctx->cfg.theta, T->range,                                 \
+                       (unsigned long long*)T->walk_counters, T->err_flag, out_by_rank, T->quad, perm, cost)
     if (ctx->counting) {
         if (quad) { NB_WALK(true, true); }
         else { NB_WALK(true, false); }
@@ -1383,7 +1255,7 @@ void nb_tree_destroy(nbody_ctx* ctx) {
         if (T->hidx[k]) (void)hipFree(T->hidx[k]);
     }
     void* ptrs[] = {T->lo, T->top, T->flags, T->body_node, T->rs_counts, T->row_total, T->blk,
-                    T->lvl_total, T->lvl_start, T->nodes, T->node_head, T->bmin, T->bmax, T->aux, T->quad, T->export_buf, T->shard_order, T->shard_blk,
+                    T->lvl_total, T->lvl_start, T->nodes, T->node_head, T->bmin, T->bmax, T->range, T->quad, T->export_buf, T->shard_order, T->shard_blk,
                     T->walk_counters, T->err_flag, T->wave_cost, T->wave_perm, T->user_order};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -1426,7 +1298,7 @@ int nb_tree_build(nbody_ctx* ctx, const float4* posm_in) {
     NB_HIP(ctx, hipEventRecord(T->lvl_ready, st));
     auto emit = [&]() {
         hipLaunchKernelGGL(k_emit, dim3(T->pf_nb), dim3(256), 0, st, T->keys[cur], T->idx[cur], posm_in, n, D, T->lo, T->top,
-                           T->flags, T->blk, T->pf_nb, T->lvl_start, T->nodes, T->bmin, T->bmax, T->aux, T->node_head,
+                           T->flags, T->blk, T->pf_nb, T->lvl_start, T->nodes, T->bmin, T->bmax, T->range, T->node_head,
                            T->body_node, (uint32_t)T->cap_nodes, T->err_flag);
     };
     emit();
@@ -1453,7 +1325,7 @@ int nb_tree_build(nbody_ctx* ctx, const float4* posm_in) {
     }
     if (T->h_lvl_start[LIST_ROW + 1] > T->h_lvl_start[LIST_ROW] || T->h_lvl_start[D + 1] > T->h_lvl_start[D]) {
         hipLaunchKernelGGL(k_leaflist, dim3((n + 255) / 256), dim3(256), 0, st, T->keys[cur], T->idx[cur], posm_in, n,
-                           ctx->cfg.leaflist_mode, T->flags, T->body_node, T->nodes, T->bmin, T->bmax, T->aux, T->node_head,
+                           ctx->cfg.leaflist_mode, T->flags, T->body_node, T->nodes, T->bmin, T->bmax, T->range, T->node_head,
                            (uint32_t)T->cap_nodes, mac);
         NB_HIP(ctx, hipGetLastError());
     }
@@ -1461,10 +1333,9 @@ int nb_tree_build(nbody_ctx* ctx, const float4* posm_in) {
         const uint32_t first = T->h_lvl_start[d], count = T->h_lvl_start[d + 1] - first;
         if (!count) continue;
         // the children of level d are the nodes of level d + 1
-        hipLaunchKernelGGL(k_aggregate, dim3((count + 255) / 256), dim3(256), 0, st, T->nodes, T->bmin, T->bmax, T->aux,
+        hipLaunchKernelGGL(k_aggregate, dim3((count + 255) / 256), dim3(256), 0, st, T->nodes, T->bmin, T->bmax, T->range,
                            first, count, T->h_lvl_start[d + 2], mac);
     }
-    hipLaunchKernelGGL(k_rope_resolve, dim3(((uint32_t)total + 255) / 256), dim3(256), 0, st, T->aux, (uint32_t)total);
     if (T->quad) {
         for (int d = D; d >= 0; --d) {
             const uint32_t first = T->h_lvl_start[d], count = T->h_lvl_start[d + 1] - first;
@@ -1640,7 +1511,7 @@ int nb_tree_device_nodes(nbody_ctx* ctx, void** ptr, size_t* bytes) {
     const uint32_t cnt = (uint32_t)T->n_nodes;
     if (!T->export_is_upload) {  // an uploaded tree is kept as it came (renumbered); a built one is exported
         hipLaunchKernelGGL(k_export, dim3((cnt + 255) / 256), dim3(256), 0, ctx->stream, T->nodes, T->bmin, T->bmax,
-                           T->aux, T->node_head, T->keys[T->sorted], T->lvl_start, (int)T->D, cnt, T->octree_rs ? 1 : 0,
+                           T->range, T->node_head, T->keys[T->sorted], T->lvl_start, (int)T->D, cnt, T->octree_rs ? 1 : 0,
                            T->export_buf);
         NB_HIP(ctx, hipGetLastError());
     }
@@ -1711,8 +1582,7 @@ int nb_tree_upload(nbody_ctx* ctx, const nbody_octree_node* host_nodes, uint64_t
     NB_HIP(ctx, hipMemcpyAsync(T->export_buf, renum.data(), kept * sizeof(nbody_octree_node), hipMemcpyHostToDevice, ctx->stream));
     const uint32_t cnt = (uint32_t)kept;
     hipLaunchKernelGGL(k_import, dim3((cnt + 255) / 256), dim3(256), 0, ctx->stream, T->export_buf, cnt, T->nodes, T->bmin,
-                       T->bmax, T->aux, mac_scale(ctx), T->err_flag);
-    hipLaunchKernelGGL(k_rope_resolve, dim3((cnt + 255) / 256), dim3(256), 0, ctx->stream, T->aux, cnt);
+                       T->bmax, T->range, mac_scale(ctx), T->err_flag);
     NB_HIP(ctx, hipGetLastError());
     NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     T->n_nodes = kept;

@@ -66,6 +66,21 @@ def test_hip_matches_golden(path):
             keys, depth, _ = sim.morton_keys()
             assert np.array_equal(keys, g["keys"]) and np.array_equal(depth, g["leaf_depth"])
             assert len(sim.download_octree()) == len(nodes)
+    if n == 4096:
+        # Configuration 1 at its own size: 100 steps of src/nbody_cpu.rs:319-360.  The unsoftened r^-5
+        # law throws bodies out through close encounters (the oracle's state reaches |pos| ~ 1e14), and
+        # such an encounter amplifies any rounding difference without bound, so the state is compared
+        # where it is comparable: every body finite on both sides, the median body bit-close, nine
+        # bodies in ten within 1e-3 (measured: median 0, 93 % within 1e-3, 84 % within 1e-4 of their
+        # displacement; tools/cpu100_check.py).
+        with nb.NBodySim(n, law=0, integrator=0) as sim:
+            sim.upload(m, pos)
+            sim.upload_alt(pos)
+            sim.step_allpairs(100)
+            p, v, a = sim.download()
+        d = np.linalg.norm((p - g["cpu100_pos"])[:, :3].astype(np.float64), axis=1)
+        assert np.isfinite(p).all() and np.isfinite(g["cpu100_pos"]).all()
+        assert np.median(d) <= 1e-6 and (d < 1e-3).mean() >= 0.9, (float(np.median(d)), float((d < 1e-3).mean()))
     if "wgsl20_pos" in g:
         with nb.NBodySim(n, law=1) as sim:
             sim.upload(m, pos, vel)

@@ -87,37 +87,89 @@ def test_pair_parts_sum_to_the_whole_at_1m():
     assert err.max() < 2e-6, float(err.max())
 
 
+# Largest distance of the GPU result from the f32 sum in the reference's order measured at these
+# configurations (profiles/r02_parity.json: 5.5e-5 / 5.0e-5 / 5.9e-5 all-pairs at N = 1M, 1.5e-5 at
+# N = 65,536, 2.9e-5 Barnes-Hut at 1M; at 16M 8.1e-6 / 9.0e-6 over a run of the index order and 5.5e-5 /
+# 2.9e-5 over the bodies next to the plane x = world / 2, whose terms cancel most), with half as much
+# again: a regression guard on top of the bounds above, which move with the reference's own drift.
+MEASURED_MAX_VS_F32 = {"allpairs_1m": 9e-5, "allpairs_65536": 2.3e-5, "bh_1m": 4.5e-5, "bh_16m": 8.5e-5}
+
+
+def test_measured_maxima_hold_as_regression_bounds(par):
+    n = 1 << 20
+    for law in ("plummer", "wgsl_bias"):
+        m, pos, vel, acc, _ = _acc(n, LAWS[law])
+        st = par.allpairs_stats(LAWS[law], m, pos, vel, acc, par.slices_of(n))
+        assert st["vs_f32_reference_order"]["max"] < MEASURED_MAX_VS_F32["allpairs_1m"], (law, st)
+    m, pos, vel, acc, _ = _acc(65536, LAWS["wgsl_bias"])
+    st = par.allpairs_stats(LAWS["wgsl_bias"], m, pos, vel, acc, [(0, 65536)])
+    assert st["vs_f32_reference_order"]["max"] < MEASURED_MAX_VS_F32["allpairs_65536"], st
+
+
+def _target_sets(pos, n, sample):
+    """Index sets of targets: a run of the index order (bodies are indexed at random, so this is a
+    spatially random sample), the outermost bodies of the halo (deep, sparse paths and long chains of
+    single-child cells), and the bodies closest to the plane x = world / 2 on both sides of it (the
+    boundary between top-level octants, where Morton-adjacent bodies are far apart in the tree)."""
+    b = (n // 2) // 64 * 64
+    r = np.linalg.norm(pos[:, :3].astype(np.float64) - 125.0, axis=1)
+    halo = np.argsort(r)[-sample:]
+    plane = np.argsort(np.abs(pos[:, 0].astype(np.float64) - 125.0))[:sample]
+    return {"index run": np.arange(b, b + sample), "outer halo": np.sort(halo), "octant boundary": np.sort(plane)}
+
+
 @pytest.mark.parametrize("n,sample", [(1 << 20, 4096), (1 << 24, 2048)])
 @pytest.mark.parametrize("law", ["plummer", "wgsl_bias"])
 def test_barnes_hut_traversal_against_the_oracle_on_the_same_tree(law, n, sample):
     """Configs 4 and 5: the GPU-built octree is downloaded and the oracle's per-thread traversal
-    (src/nbodybh.wgsl:63-161) walks the SAME tree bytes for a run of targets in the middle of the
-    body range (the centre of the sphere, where a body's ~1,600 terms nearly cancel).  Per body:
-    within 1e-5 of the f32 reference walk up to that walk's own rounding error against its f64
-    evaluation (the bound of tests/test_octree_gpu.py) and an absolute rounding floor of 3e-6 of
-    the sample's median acceleration -- f32 sums of terms far larger than their resultant cannot be
-    held to 1e-5 of the resultant by either side: the reference walk itself is up to 1.6e-5 from
-    its own f64 evaluation on these bodies.  The 99th percentile is held to the plain 1e-5."""
+    (src/nbodybh.wgsl:63-161) walks the SAME tree bytes for three sets of targets (see _target_sets).
+    Per body: within 1e-5 of the f32 reference walk up to that walk's own rounding error against its
+    f64 evaluation and the f32 floor of any summation order, 4 eps x the sum of the terms' magnitudes
+    (the bound of tests/test_octree_gpu.py) -- f32 sums of ~1,600 terms far larger than their
+    resultant cannot be held to 1e-5 of the resultant by either side.  The 99th percentile is held to
+    the plain 1e-5, and the visit / interaction counts of every set equal the oracle's."""
     import nbody_amd as nb
     from oracle import oracle as orc
     m, pos, vel = nb.gen_plummer(n, seed=42, equilibrium=True)
+    sets = _target_sets(pos, n, sample)
+    counted = {}
     with nb.NBodySim(n, law=LAWS[law]) as sim:
         sim.upload(m, pos, vel)
         sim.build_octree()
         nodes = sim.download_octree().view(orc.NODE_DTYPE)
         acc = sim.accel_bh()
-    b = (n // 2) // 64 * 64
-    r32, _ = orc.bh_accel(LAWS[law], pos, vel, nodes, i_begin=b, i_count=sample)
-    r64 = orc.bh_accel_f64(LAWS[law], pos, vel, nodes, i_begin=b, i_count=sample)
-    r64 = r64[b:b + sample] if len(r64) == n else r64
-    a = acc[b:b + sample, :3].astype(np.float64)
-    r32 = r32[b:b + sample, :3].astype(np.float64)
-    scale = np.linalg.norm(r64, axis=1)
-    e_gpu = np.linalg.norm(a - r64, axis=1)
-    e_ref = np.linalg.norm(r32 - r64, axis=1)
-    bound = 1e-5 * scale + e_ref + 3e-6 * np.median(scale)
-    bad = e_gpu > bound
-    assert not bad.any(), (int(bad.sum()), float((e_gpu / scale).max()))
-    e32 = np.linalg.norm(a - r32, axis=1)
-    assert not (e32 > bound + e_ref).any(), float((e32 / scale).max())
-    assert np.quantile(e32 / np.linalg.norm(r32, axis=1), 0.99) < 1e-5
+        # counts of the counting traversal for (up to 64 runs of consecutive sorted ranks of) each set
+        _, _, sorted_order = sim.morton_keys()
+        rank_of = np.empty(n, np.int64)
+        rank_of[sorted_order] = np.arange(n)
+        sim.set_counting(True)
+        for what, idx in sets.items():
+            ranks = np.sort(rank_of[idx])
+            runs = np.split(ranks, np.flatnonzero(np.diff(ranks) != 1) + 1)[:64]
+            got = np.zeros(3, np.int64)
+            for run in runs:
+                sim.bh_forces_ranked(int(run[0]), len(run))
+                c = sim.counters()
+                got += (c["bh_node_visits"], c["bh_leaf_interactions"], c["bh_aggregate_interactions"])
+            counted[what] = (tuple(int(x) for x in got), sorted_order[np.concatenate(runs)])
+    worst = 0.0
+    for what, idx in sets.items():
+        tp, tv = np.ascontiguousarray(pos[idx]), np.ascontiguousarray(vel[idx])
+        r32, cnt = orc.bh_accel(LAWS[law], tp, tv, nodes)
+        r64, mag = orc.bh_accel_f64(LAWS[law], tp, tv, nodes, with_abs=True)
+        a = acc[idx, :3].astype(np.float64)
+        r32 = r32[:, :3].astype(np.float64)
+        scale = np.linalg.norm(r64, axis=1)
+        e_gpu = np.linalg.norm(a - r64, axis=1)
+        e_ref = np.linalg.norm(r32 - r64, axis=1)
+        bound = 1e-5 * scale + e_ref + 4 * np.finfo(np.float32).eps * mag
+        bad = e_gpu > bound
+        assert not bad.any(), (what, int(bad.sum()), float((e_gpu / scale).max()))
+        e32 = np.linalg.norm(a - r32, axis=1)
+        assert not (e32 > bound + e_ref).any(), (what, float((e32 / scale).max()))
+        assert np.quantile(e32 / np.linalg.norm(r32, axis=1), 0.99) < 1e-5, what
+        worst = max(worst, float((e32 / np.linalg.norm(r32, axis=1)).max()))
+        got, sel = counted[what]
+        _, want = orc.bh_accel(LAWS[law], np.ascontiguousarray(pos[sel]), np.ascontiguousarray(vel[sel]), nodes)
+        assert got == (want["visits"], want["leaf"], want["aggregate"]), what
+    assert worst < MEASURED_MAX_VS_F32["bh_1m" if n == 1 << 20 else "bh_16m"], worst

@@ -142,3 +142,50 @@ def test_an_uploaded_interior_node_without_children_is_refused(orc):
         assert e.value.code == -1 and "no children" in str(e.value)
         sim.upload_octree(nodes.view(nb.NODE_DTYPE))   # the intact tree still goes in
         assert np.isfinite(sim.accel_bh()).all()
+
+
+def test_bodies_piled_up_by_the_clamp_are_walked_like_the_reference(orc):
+    """A run long enough for the Barnes-Hut clamp (src/nbodybh.wgsl:167) to pile escapers on the faces
+    and in a corner of the world cube: bodies with equal coordinates share depth-cap cells and end in
+    leaf lists.  On the tree bytes of that state the counting traversal must make the oracle's visits and
+    interactions, for targets inside the pile, on a face and in the bulk."""
+    n = 12000
+    m, p = nb.gen_refcube(n, seed=21)
+    v = np.zeros((n, 4), np.float32)
+    rng = np.random.default_rng(3)
+    v[:3000, :3] = 120.0 + 30.0 * rng.random((3000, 3)).astype(np.float32)      # towards the corner (250, 250, 250)
+    v[3000:5000, 0] = -150.0                                                     # towards the face x = 0
+    with nb.NBodySim(n, law=nb.LAW_PLUMMER) as sim:
+        sim.upload(m, p, v)
+        sim.step_bh(25)
+        pos, vel, _ = sim.download()
+        assert np.isfinite(pos).all()
+        corner = np.flatnonzero((pos[:, :3] == 250.0).all(axis=1))
+        face = np.flatnonzero((pos[:, 0] == 0.0) & ~(pos[:, 1:3] == 250.0).any(axis=1))
+        assert len(corner) >= 2900 and len(face) >= 1900, (len(corner), len(face))
+        sim.build_octree()
+        nodes = sim.download_octree()
+        lists = nodes[nodes["node_type"] == nb.NODE_LEAFLIST]
+        assert lists["child"][:, 1].max() >= len(corner) - 1       # the corner pile is ONE leaf list (literal mode: k - 1 members)
+        acc = sim.accel_bh()
+    onodes = np.ascontiguousarray(nodes.view(orc.NODE_DTYPE))
+    bulk = np.setdiff1d(np.arange(n), np.concatenate([corner, face]))
+    for what, idx in (("corner pile", corner[:96]), ("face", face[:96]), ("bulk", bulk[:96])):
+        tp, tv = np.ascontiguousarray(pos[idx]), np.ascontiguousarray(vel[idx])
+        ref, rc = orc.bh_accel(orc.LAW_PLUMMER, tp, tv, onodes)
+        got = np.zeros(3, np.int64)
+        for b in idx:
+            with nb.NBodySim(n, law=nb.LAW_PLUMMER, shard_begin=int(b), shard_count=1) as one:
+                one.upload(m, pos, vel)
+                one.build_octree()
+                one.set_counting(True)
+                one.accel_bh()
+                c = one.counters()
+            got += (c["bh_node_visits"], c["bh_leaf_interactions"], c["bh_aggregate_interactions"])
+            if got[0] > 0 and b == idx[7]:
+                break                      # eight single-target contexts per set are enough for the counts
+        _, rc8 = orc.bh_accel(orc.LAW_PLUMMER, tp[:8], tv[:8], onodes)
+        assert tuple(got) == (rc8["visits"], rc8["leaf"], rc8["aggregate"]), what
+        r = ref[:, :3].astype(np.float64)
+        g = acc[idx, :3].astype(np.float64)
+        assert (np.linalg.norm(g - r, axis=1) <= 2e-4 * np.linalg.norm(r, axis=1) + 1e-9).all(), what

@@ -274,6 +274,35 @@ int nbody_morton_keys(nbody_ctx* ctx, uint64_t* host_keys, uint8_t* host_leaf_de
  * the same order whoever shares its wavefront; only the time does. */
 int nbody_bh_set_target_order(nbody_ctx* ctx, const uint32_t* host_order, uint64_t count);
 
+/* Domain-decomposed octree build; no counterpart in the reference, which builds ONE tree on one host
+ * every frame (src/nbody_gpu_bh.rs:452, src/octree_maxdepth.rs:26-61).  With domains >= 2 every build
+ * of this (unsharded) context deals the bodies to `domains` domains -- runs of whole depth-top_levels
+ * cells in Morton order holding about n_bodies / domains bodies each -- builds each domain's tree from
+ * its own bodies alone (work in proportion to its share: what one GPU of several would do), and
+ * rebuilds the cells above depth top_levels from the domains' depth-top_levels cells (the "top tree",
+ * the only part every domain must hold).  The traversal runs over the merged tree, whose nodes are
+ * those of the one tree over all bodies, bit for bit: accelerations, visit and interaction counts do
+ * not change.  domains <= 32, 1 <= top_levels <= 6 and below max_depth; domains <= 1 switches back.
+ * Not with max_depth 0 or quadrupoles; nbody_download_octree and leaf depths are not available while on.
+ * nbody_bh_domain_stats (after a build; blocks): sizes and times of the last build, and -- after a
+ * COUNTING traversal of all bodies (nbody_set_counting) -- how many nodes of OTHER domains' trees each
+ * domain's targets visited: the nodes it would have to import if every domain sat on its own GPU. */
+typedef struct nbody_domain_stats_t {
+    uint32_t domains, top_levels;
+    uint64_t top_entries;        /* depth-top_levels cells and lone bodies handed to the top tree */
+    uint64_t top_nodes;          /* nodes of the top tree (replicated on every domain) */
+    uint64_t merged_nodes;       /* nodes of the merged tree = those of the one tree over all bodies */
+    uint64_t top_nodes_visited;  /* top-tree nodes some target visited (last counting traversal) */
+    double partition_ms;         /* dealing the bodies to the domains */
+    double merge_ms;             /* nodes into the merged array, merged sorted order, top tree */
+    uint64_t bodies[32];
+    uint64_t nodes[32];          /* nodes of each domain's own tree */
+    uint64_t imported_nodes[32]; /* per domain: nodes of other domains' trees its targets visited */
+    double build_ms[32];         /* each domain's own build (gather of its bodies + the ordinary builder) */
+} nbody_domain_stats_t;
+int nbody_bh_set_domains(nbody_ctx* ctx, uint32_t domains, uint32_t top_levels);
+int nbody_bh_domain_stats(nbody_ctx* ctx, nbody_domain_stats_t* out);
+
 /* Replaces the position readback of src/nbody_gpu_bh.rs:496-516 (and extends it to all state).
  * Any pointer may be NULL.  The pad lane of host_pos16 is written as 0. */
 int nbody_download(nbody_ctx* ctx, float* host_pos16, float* host_vel16, float* host_acc16);

@@ -47,6 +47,23 @@ class NBodyCounters(C.Structure):
     ]
 
 
+class NBodyDomainStats(C.Structure):
+    _fields_ = [
+        ("domains", C.c_uint32),
+        ("top_levels", C.c_uint32),
+        ("top_entries", C.c_uint64),
+        ("top_nodes", C.c_uint64),
+        ("merged_nodes", C.c_uint64),
+        ("top_nodes_visited", C.c_uint64),
+        ("partition_ms", C.c_double),
+        ("merge_ms", C.c_double),
+        ("bodies", C.c_uint64 * 32),
+        ("nodes", C.c_uint64 * 32),
+        ("imported_nodes", C.c_uint64 * 32),
+        ("build_ms", C.c_double * 32),
+    ]
+
+
 # every symbol include/nbody_hip.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 _F = C.POINTER(C.c_float)
@@ -76,6 +93,8 @@ SYMBOLS = {
     "nbody_upload_octree": (C.c_int, [_P, _P, C.c_uint64]),
     "nbody_morton_keys": (C.c_int, [_P, _P, _P, _P]),
     "nbody_bh_set_target_order": (C.c_int, [_P, _P, C.c_uint64]),
+    "nbody_bh_set_domains": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    "nbody_bh_domain_stats": (C.c_int, [_P, C.POINTER(NBodyDomainStats)]),
     "nbody_download": (C.c_int, [_P, _P, _P, _P]),
     "nbody_download_alt": (C.c_int, [_P, _P, _P, _P]),
     "nbody_sync": (C.c_int, [_P]),

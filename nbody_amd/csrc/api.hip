@@ -542,6 +542,24 @@ int nbody_bh_set_target_order(nbody_ctx* ctx, const uint32_t* host_order, uint64
     });
 }
 
+int nbody_bh_set_domains(nbody_ctx* ctx, uint32_t domains, uint32_t top_levels) {
+    if (!ctx) return NBODY_ERR_INVALID;
+    return guarded(ctx, [&]() -> int {
+        int r = set_device(ctx);
+        if (r) return r;
+        return nb_tree_set_domains(ctx, domains, top_levels);
+    });
+}
+
+int nbody_bh_domain_stats(nbody_ctx* ctx, nbody_domain_stats_t* out) {
+    if (!ctx || !out) return NBODY_ERR_INVALID;
+    return guarded(ctx, [&]() -> int {
+        int r = set_device(ctx);
+        if (r) return r;
+        return nb_tree_domain_stats(ctx, out);
+    });
+}
+
 int nbody_download(nbody_ctx* ctx, float* host_pos16, float* host_vel16, float* host_acc16) {
     if (!ctx) return NBODY_ERR_INVALID;
     if (!ctx->uploaded) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_download: no bodies uploaded");

@@ -129,5 +129,7 @@ int nb_tree_download(nbody_ctx* ctx, nbody_octree_node* host_nodes, uint64_t cap
 int nb_tree_upload(nbody_ctx* ctx, const nbody_octree_node* host_nodes, uint64_t n_nodes);
 int nb_tree_keys(nbody_ctx* ctx, uint64_t* keys, uint8_t* depth, uint32_t* order);
 int nb_tree_set_target_order(nbody_ctx* ctx, const uint32_t* host_order, uint64_t count);
+int nb_tree_set_domains(nbody_ctx* ctx, uint32_t domains, uint32_t top_levels);
+int nb_tree_domain_stats(nbody_ctx* ctx, nbody_domain_stats_t* out);
 void nb_tree_forget_order(nbody_ctx* ctx);  // new bodies: the kept grouping of the traversal's targets no longer fits
 int nb_tree_device_nodes(nbody_ctx* ctx, void** ptr, size_t* bytes);

@@ -82,8 +82,12 @@ static_assert(sizeof(QNode) == 32, "node record layout");
 
 }  // namespace
 
+struct Domains;
+struct TopPatch;
+
 struct Octree {
-    uint64_t n = 0;
+    uint64_t n = 0;      // bodies of the present build
+    uint64_t n_cap = 0;  // bodies the per-body arrays hold
     uint32_t D = 16;
     // sort buffers
     uint64_t* keys[2] = {nullptr, nullptr};
@@ -142,6 +146,8 @@ struct Octree {
     uint32_t* hidx[2] = {nullptr, nullptr};
     const uint32_t* horder = nullptr;  // hidx[0] or hidx[1] once made
     uint32_t horder_age = 0;           // builds since it was made
+    // domain-decomposed build (nbody_bh_set_domains): local trees of the domains and the merged top
+    Domains* dom = nullptr;
 };
 
 namespace {
@@ -438,9 +444,12 @@ __device__ __forceinline__ int common_levels(uint64_t a, uint64_t b, int D) {
 
 // flags: bit0 = contributes a leaf-list member node, bit1 = first body of a depth-cap cell
 // holding >= 2 bodies, bit2 = member of such a cell.
+// multi (optional, per body index): the entry stands for a whole cell of >= 2 bodies at depth D, which
+// exists down to that depth whatever its neighbours (the top tree over the domains' cells).
 __global__ __launch_bounds__(256) void k_prefix(const uint64_t* __restrict__ keys, uint32_t n, int D, int list_mode,
                                                 uint8_t* __restrict__ lo, uint8_t* __restrict__ top,
-                                                uint8_t* __restrict__ flags, uint32_t* __restrict__ blk, uint32_t nb) {
+                                                uint8_t* __restrict__ flags, uint32_t* __restrict__ blk, uint32_t nb,
+                                                const uint32_t* __restrict__ idx, const uint8_t* __restrict__ multi) {
     __shared__ uint32_t sh[NCNT];
     const int tid = threadIdx.x, lane = tid & 63;
     if (tid < NCNT) sh[tid] = 0;
@@ -455,6 +464,7 @@ __global__ __launch_bounds__(256) void k_prefix(const uint64_t* __restrict__ key
         const int Ln = (i + 1 == n) ? -1 : common_levels(k, keys[i + 1], D);
         l = Lp + 1;
         t = min(D, max(Lp, Ln) + 1);
+        if (multi && multi[idx[i]]) t = D;
         const bool inlist = (Lp == D) || (Ln == D);
         const bool member = list_mode ? inlist : (inlist && Ln == D);
         f = (member ? 1u : 0u) | ((Lp < D && Ln == D) ? 2u : 0u) | (inlist ? 4u : 0u);
@@ -549,57 +559,99 @@ __global__ __launch_bounds__(256) void k_emit(const uint64_t* __restrict__ keys,
 }
 
 // ---- 6. depth-cap cells -------------------------------------------------------------------
-// One thread per cell: the reference's aggregate recurrence over the cell's bodies in index
-// order, and the list members it creates (src/octree_maxdepth.rs:91-136).
-__global__ void k_leaflist(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idx,
-                           const float4* __restrict__ posm, uint32_t n, int list_mode, const uint8_t* __restrict__ flags,
-                           const uint32_t* __restrict__ body_node, QNode* __restrict__ nodes, float4* __restrict__ bmin,
-                           float4* __restrict__ bmax, float* __restrict__ range, uint32_t* __restrict__ node_head,
-                           uint32_t cap_nodes, MacScale mac) {
+// The reference's aggregate recurrence over a cell's bodies in index order, and the list members it
+// creates (src/octree_maxdepth.rs:91-136).  The recurrence is a chain of f32 roundings (each new
+// centre is ((c m) + (p_b m_b)) / (m + m_b) of the previous one), so it stays sequential; what a
+// wavefront does together is everything around it: a cell's bodies are loaded 64 at a time, every
+// lane follows the chain (so each holds the aggregate as it stood before its own body, which is the
+// literal list member), the box is a reduction, and the member records go out side by side.  A
+// wavefront takes the cells headed by its 64 sorted bodies one after the other.  (One thread per
+// cell, each load waiting for the one before, took 50 ms for 100,000 bodies in one cell.)
+__global__ __launch_bounds__(256) void k_leaflist(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idx,
+                                                  const float4* __restrict__ posm, uint32_t n, int list_mode,
+                                                  const uint8_t* __restrict__ flags, const uint32_t* __restrict__ body_node,
+                                                  QNode* __restrict__ nodes, float4* __restrict__ bmin, float4* __restrict__ bmax,
+                                                  float* __restrict__ range, uint32_t* __restrict__ node_head, uint32_t cap_nodes,
+                                                  MacScale mac) {
+    const int lane = threadIdx.x & 63;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || !(flags[i] & 2u)) return;
-    const uint32_t id = body_node[i];
-    if (id >= cap_nodes) return;
-    QNode nd = nodes[id];
-    const uint64_t key = keys[i];
-    uint32_t member = nd.first;
-    uint32_t count = 0;
-    float4 a = posm[idx[i]];  // aggregate: xyz = centre of mass, w = mass
-    float mnx = a.x, mny = a.y, mnz = a.z, mxx = a.x, mxy = a.y, mxz = a.z;
-    auto put = [&](float4 q) {
-        if (member < cap_nodes) {
-            QNode c;
-            c.cx = q.x; c.cy = q.y; c.cz = q.z; c.mass = q.w;
-            c.r2_open = c.r2_accept = QN_ALWAYS;
-            c.first = 0;
-            c.count_type = qn_pack(0, NBODY_NODE_LEAFBODY);
-            nodes[member] = c;
-            node_head[member] = i;
+    unsigned long long heads = __ballot(i < n && (flags[min(i, n - 1)] & 2u));
+    const uint32_t wave0 = i - (uint32_t)lane;
+    while (heads) {
+        const int h = (int)__builtin_ctzll(heads);
+        heads &= heads - 1;
+        const uint32_t ih = wave0 + (uint32_t)h;  // the cell's first body (wave-uniform)
+        const uint32_t id = body_node[ih];
+        if (id >= cap_nodes) continue;
+        QNode nd = nodes[id];
+        const uint64_t key = keys[ih];
+        uint32_t member = nd.first, count = 0;
+        float4 a = posm[idx[ih]];  // aggregate: xyz = centre of mass, w = mass
+        float mnx = a.x, mny = a.y, mnz = a.z, mxx = a.x, mxy = a.y, mxz = a.z;
+        auto put = [&](uint32_t slot, float4 q) {
+            if (slot < cap_nodes) {
+                QNode c;
+                c.cx = q.x; c.cy = q.y; c.cz = q.z; c.mass = q.w;
+                c.r2_open = c.r2_accept = QN_ALWAYS;
+                c.first = 0;
+                c.count_type = qn_pack(0, NBODY_NODE_LEAFBODY);
+                nodes[slot] = c;
+                node_head[slot] = ih;
+            }
+        };
+        if (list_mode) {  // every body of the cell is a member, the first one included
+            if (lane == 0) put(member, a);
+            ++member;
+            ++count;
         }
-        ++member;
-        ++count;
-    };
-    if (list_mode) put(a);
-    for (uint32_t j = i + 1; j < n && keys[j] == key; ++j) {
-        const float4 b = posm[idx[j]];
-        if (!list_mode) put(a);  // literal: the member is the PREVIOUS aggregate (node_a_*)
-        else put(b);
-        const float tm = a.w + b.w;
-        a.x = ((a.x * a.w) + (b.x * b.w)) / tm;
-        a.y = ((a.y * a.w) + (b.y * b.w)) / tm;
-        a.z = ((a.z * a.w) + (b.z * b.w)) / tm;
-        a.w = tm;
-        mnx = fminf(mnx, b.x); mny = fminf(mny, b.y); mnz = fminf(mnz, b.z);
-        mxx = fmaxf(mxx, b.x); mxy = fmaxf(mxy, b.y); mxz = fmaxf(mxz, b.z);
+        for (uint32_t base = ih + 1; base < n; base += 64) {
+            const uint32_t j = base + (uint32_t)lane;
+            const bool ok = j < n && keys[min(j, n - 1)] == key;  // equal keys are consecutive: the lanes that hold are a prefix
+            const int cnt = __popcll(__ballot(ok));
+            if (cnt == 0) break;
+            float4 b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (ok) b = posm[idx[j]];
+            const float bwx = b.x * b.w, bwy = b.y * b.w, bwz = b.z * b.w;
+            float4 before = a;  // the aggregate as it stood before this lane's body
+            for (int k = 0; k < cnt; ++k) {
+                const float m_k = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, b.w), k));
+                const float x_k = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bwx), k));
+                const float y_k = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bwy), k));
+                const float z_k = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bwz), k));
+                if (lane == k) before = a;
+                const float tm = a.w + m_k;
+                a.x = ((a.x * a.w) + x_k) / tm;
+                a.y = ((a.y * a.w) + y_k) / tm;
+                a.z = ((a.z * a.w) + z_k) / tm;
+                a.w = tm;
+            }
+            // the box of the chunk's bodies (min and max are exact in any order)
+            float lx = ok ? b.x : INFINITY, ly = ok ? b.y : INFINITY, lz = ok ? b.z : INFINITY;
+            float hx = ok ? b.x : -INFINITY, hy = ok ? b.y : -INFINITY, hz = ok ? b.z : -INFINITY;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                lx = fminf(lx, __shfl_xor(lx, o, 64)); ly = fminf(ly, __shfl_xor(ly, o, 64)); lz = fminf(lz, __shfl_xor(lz, o, 64));
+                hx = fmaxf(hx, __shfl_xor(hx, o, 64)); hy = fmaxf(hy, __shfl_xor(hy, o, 64)); hz = fmaxf(hz, __shfl_xor(hz, o, 64));
+            }
+            mnx = fminf(mnx, lx); mny = fminf(mny, ly); mnz = fminf(mnz, lz);
+            mxx = fmaxf(mxx, hx); mxy = fmaxf(mxy, hy); mxz = fmaxf(mxz, hz);
+            // literal: the member is the PREVIOUS aggregate (node_a_*); else the body itself
+            if (ok) put(member + (uint32_t)lane, list_mode ? b : before);
+            member += (uint32_t)cnt;
+            count += (uint32_t)cnt;
+            if (cnt < 64) break;
+        }
+        if (lane == 0) {
+            nd.cx = a.x; nd.cy = a.y; nd.cz = a.z; nd.mass = a.w;
+            const float rg = fmaxf(mxx - mnx, fmaxf(mxy - mny, mxz - mnz));
+            qn_set_range(nd, rg, mac);
+            nd.count_type = qn_pack(count, NBODY_NODE_LEAFLIST);
+            nodes[id] = nd;
+            range[id] = rg;
+            bmin[id] = make_float4(mnx, mny, mnz, 0.0f);
+            bmax[id] = make_float4(mxx, mxy, mxz, 0.0f);
+        }
     }
-    nd.cx = a.x; nd.cy = a.y; nd.cz = a.z; nd.mass = a.w;
-    const float rg = fmaxf(mxx - mnx, fmaxf(mxy - mny, mxz - mnz));
-    qn_set_range(nd, rg, mac);
-    nd.count_type = qn_pack(count, NBODY_NODE_LEAFLIST);
-    nodes[id] = nd;
-    range[id] = rg;
-    bmin[id] = make_float4(mnx, mny, mnz, 0.0f);
-    bmax[id] = make_float4(mxx, mxy, mxz, 0.0f);
 }
 
 // ---- 7. aggregates ------------------------------------------------------------------------
@@ -882,7 +934,8 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(7,
                                               unsigned long long* __restrict__ counters,
                                               uint32_t* __restrict__ err_flag, int out_by_rank,
                                               const float* __restrict__ quad, const uint32_t* __restrict__ perm,
-                                              uint32_t* __restrict__ wave_cost) {
+                                              uint32_t* __restrict__ wave_cost, uint32_t* __restrict__ mark,
+                                              const uint32_t* __restrict__ dom_off, uint32_t n_dom) {
     __shared__ uint4 stack[WALK_STACK];  // {first, count, mask.lo, mask.hi}
     const int lane = threadIdx.x;
     // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2): give each XCD one
@@ -909,6 +962,15 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(7,
     }
     float ax = 0.0f, ay = 0.0f, az = 0.0f;
     uint32_t n_visit = 0, n_leaf = 0, n_agg = 0, n_wave = 0, max_top = 0;
+    // (counting build, domain-decomposed tree) the domain this wavefront's targets belong to, as a bit:
+    // every node it visits is marked with it
+    uint32_t my_domain_bit = 0;
+    if (COUNT && mark) {
+        uint32_t d = 0;
+        const uint32_t r0 = i_begin + blk * WALK_THREADS;
+        while (d + 1 < n_dom && dom_off[d + 1] <= r0) ++d;
+        my_domain_bit = 1u << d;
+    }
     int top = 0;
     const unsigned long long all = __ballot(valid);
     if (all) {
@@ -961,6 +1023,7 @@ __global__ __launch_bounds__(WALK_THREADS) __attribute__((amdgpu_waves_per_eu(7,
             auto rec = [&](const int k) __attribute__((always_inline)) {
                 const QNode nd = c[k];
                 if (COUNT) ++n_visit;
+                if (COUNT && mark && lane == (int)__builtin_ctzll(mask)) atomicOr(&mark[first + k], my_domain_bit);
                 const float dx = nd.cx - t.x, dy = nd.cy - t.y, dz = nd.cz - t.z;
                 // PLUMMER: the softened squared distance, which the thresholds are prepared for
                 const float r2 = LAW == NBODY_LAW_PLUMMER ? fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, eps2)))
@@ -1108,6 +1171,8 @@ __global__ __launch_bounds__(1024) void k_walk_order(const uint32_t* __restrict_
 
 // theta == 0 gives infinite (or, for a zero range, NaN) thresholds: nothing is accepted by
 // them and the reference's expression, evaluated in the band, opens every node as it should.
+void domain_marks(Octree* T, uint32_t** mark, const uint32_t** dom_off, uint32_t* n_dom);
+
 int env_int_or(const char* name, int dflt) {
     const char* v = std::getenv(name);
     return (v && *v) ? std::atoi(v) : dflt;
@@ -1176,10 +1241,15 @@ void launch_walk(nbody_ctx* ctx, Octree* T, const uint32_t* order, uint32_t m, c
     const bool ordered = grid.x <= 8 * ORDER_MAX && grid.x >= 64;
     const uint32_t* perm = ordered && T->perm_nblk == grid.x && T->perm_order == order ? T->wave_perm : nullptr;
     uint32_t* cost = ordered ? T->wave_cost : nullptr;
+    // a counting traversal of a domain-decomposed tree marks every visited node with its visitors' domains
+    uint32_t* mark = nullptr;
+    const uint32_t* dom_off = nullptr;
+    uint32_t n_dom = 0;
+    if (ctx->counting && T->dom && T->built) domain_marks(T, &mark, &dom_off, &n_dom);
 #define NB_WALK(COUNT, QUAD)                                                                                              \
     hipLaunchKernelGGL((k_walk<LAW, COUNT, QUAD>), grid, dim3(WALK_THREADS), 0, ctx->stream, T->nodes, order, m, i_begin, posm, \
                        vel, acc_out, ctx->cfg.G, ctx->cfg.eps2, ctx->cfg.theta, T->range,                                 \
-                       (unsigned long long*)T->walk_counters, T->err_flag, out_by_rank, T->quad, perm, cost)
+                       (unsigned long long*)T->walk_counters, T->err_flag, out_by_rank, T->quad, perm, cost, mark, dom_off, n_dom)
     if (ctx->counting) {
         if (quad) { NB_WALK(true, true); }
         else { NB_WALK(true, false); }
@@ -1206,14 +1276,11 @@ void launch_walk(nbody_ctx* ctx, Octree* T, const uint32_t* order, uint32_t m, c
 
 }  // namespace
 
-int nb_tree_create(nbody_ctx* ctx) {
-    Octree* T = new Octree;
-    ctx->tree = T;
-    T->n = ctx->n;
-    // max_depth 0: the uncapped builder of src/octree.rs, reproduced as far as 16 levels reach
-    T->D = ctx->cfg.max_depth ? ctx->cfg.max_depth : 16;
-    T->octree_rs = ctx->cfg.max_depth == 0;
-    const uint64_t n = T->n;
+// The per-body arrays and scan workspaces of one tree, for up to n_cap bodies.
+static int tree_alloc(nbody_ctx* ctx, Octree* T, uint64_t n_cap, uint32_t D) {
+    T->n = T->n_cap = n_cap;
+    T->D = D;
+    const uint64_t n = n_cap;
     T->rs_nb = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
     T->pf_nb = (uint32_t)((n + 255) / 256);
     for (int s = 0; s < 2; ++s) {
@@ -1232,23 +1299,19 @@ int nb_tree_create(nbody_ctx* ctx) {
     NB_HIP(ctx, hipHostMalloc(&T->h_lvl_start, (NCNT + 1) * sizeof(uint32_t), hipHostMallocDefault));
     NB_HIP(ctx, hipEventCreateWithFlags(&T->lvl_ready, hipEventDisableTiming));
     NB_HIP(ctx, hipMalloc(&T->walk_counters, NWALK_COUNTERS * sizeof(uint64_t)));
-    NB_HIP(ctx, hipMalloc(&T->wave_cost, 8 * ORDER_MAX * sizeof(uint32_t)));
-    NB_HIP(ctx, hipMalloc(&T->wave_perm, 8 * ORDER_MAX * sizeof(uint32_t)));
     NB_HIP(ctx, hipMalloc(&T->err_flag, sizeof(uint32_t)));
     NB_HIP(ctx, hipMemsetAsync(T->err_flag, 0, sizeof(uint32_t), ctx->stream));
-    if (ctx->i_count < ctx->n) {
-        NB_HIP(ctx, hipMalloc(&T->shard_order, ctx->i_count * sizeof(uint32_t)));
-        NB_HIP(ctx, hipMalloc(&T->shard_blk, ((n + CO_TILE - 1) / CO_TILE + 1) * sizeof(uint32_t)));
-    }
     return ensure_nodes(ctx, T, 2 * n + 1024);
 }
 
-void nb_tree_destroy(nbody_ctx* ctx) {
-    Octree* T = ctx->tree;
+static void domains_free(Octree* T);
+
+static void tree_free(Octree* T) {
     if (!T) return;
+    domains_free(T);
     for (int s = 0; s < 2; ++s) {
-        if (T->keys[s]) hipFree(T->keys[s]);
-        if (T->idx[s]) hipFree(T->idx[s]);
+        if (T->keys[s]) (void)hipFree(T->keys[s]);
+        if (T->idx[s]) (void)hipFree(T->idx[s]);
     }
     for (int k = 0; k < 2; ++k) {
         if (T->hkeys[k]) (void)hipFree(T->hkeys[k]);
@@ -1258,20 +1321,70 @@ void nb_tree_destroy(nbody_ctx* ctx) {
                     T->lvl_total, T->lvl_start, T->nodes, T->node_head, T->bmin, T->bmax, T->range, T->quad, T->export_buf, T->shard_order, T->shard_blk,
                     T->walk_counters, T->err_flag, T->wave_cost, T->wave_perm, T->user_order};
     for (void* p : ptrs)
-        if (p) hipFree(p);
-    if (T->h_lvl_start) hipHostFree(T->h_lvl_start);
-    if (T->lvl_ready) hipEventDestroy(T->lvl_ready);
+        if (p) (void)hipFree(p);
+    if (T->h_lvl_start) (void)hipHostFree(T->h_lvl_start);
+    if (T->lvl_ready) (void)hipEventDestroy(T->lvl_ready);
     delete T;
+}
+
+int nb_tree_create(nbody_ctx* ctx) {
+    Octree* T = new Octree;
+    ctx->tree = T;
+    // max_depth 0: the uncapped builder of src/octree.rs, reproduced as far as 16 levels reach
+    T->octree_rs = ctx->cfg.max_depth == 0;
+    int r = tree_alloc(ctx, T, ctx->n, ctx->cfg.max_depth ? ctx->cfg.max_depth : 16);
+    if (r) return r;
+    NB_HIP(ctx, hipMalloc(&T->wave_cost, 8 * ORDER_MAX * sizeof(uint32_t)));
+    NB_HIP(ctx, hipMalloc(&T->wave_perm, 8 * ORDER_MAX * sizeof(uint32_t)));
+    if (ctx->i_count < ctx->n) {
+        NB_HIP(ctx, hipMalloc(&T->shard_order, ctx->i_count * sizeof(uint32_t)));
+        NB_HIP(ctx, hipMalloc(&T->shard_blk, ((ctx->n + CO_TILE - 1) / CO_TILE + 1) * sizeof(uint32_t)));
+    }
+    return NBODY_OK;
+}
+
+void nb_tree_destroy(nbody_ctx* ctx) {
+    tree_free(ctx->tree);
     ctx->tree = nullptr;
 }
 
-int nb_tree_build(nbody_ctx* ctx, const float4* posm_in) {
-    Octree* T = ctx->tree;
+// What the top tree over the domains' cells takes from the domains' own trees: which of its entries
+// stand for whole cells (k_prefix), and the records, boxes and ranges its deepest nodes are given before
+// its aggregates are made (one per entry, by entry index).
+struct TopPatch {
+    const uint8_t* multi;
+    const QNode* rec;
+    const float4* bmin;
+    const float4* bmax;
+    const float* range;
+};
+
+__global__ void k_top_patch(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ body_node, uint32_t n, TopPatch p,
+                            QNode* __restrict__ nodes, float4* __restrict__ bmin, float4* __restrict__ bmax,
+                            float* __restrict__ range, uint32_t cap_nodes) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t id = body_node[i], e = idx[i];
+    if (id >= cap_nodes) return;
+    QNode r = p.rec[e];
+    // A lone body may sit above the deepest level, where its record's `first` tells the node before it
+    // where its own children end (k_aggregate): that stays.  The deepest level has no such reader.
+    if (!p.multi[e]) r.first = nodes[id].first;
+    nodes[id] = r;
+    bmin[id] = p.bmin[e];
+    bmax[id] = p.bmax[e];
+    range[id] = p.range[e];
+}
+
+// One tree over the n bodies of posm_in (n <= T->n_cap), into T's arrays.
+static int build_into(nbody_ctx* ctx, Octree* T, const float4* posm_in, uint32_t n, const TopPatch* patch) {
     const MacScale mac = mac_scale(ctx);
-    const uint32_t n = (uint32_t)T->n;
+    if (n == 0 || n > T->n_cap) return nb_fail(ctx, NBODY_ERR_CAPACITY, "octree build: more bodies than the tree was made for");
+    T->n = n;
+    T->rs_nb = (n + RS_TILE - 1) / RS_TILE;
+    T->pf_nb = (n + 255) / 256;
     const int D = (int)T->D;
     hipStream_t st = ctx->stream;
-    nb_time_begin(ctx, 2);
     hipLaunchKernelGGL(k_morton, dim3((n + 255) / 256), dim3(256), 0, st, posm_in, n, ctx->cfg.world, D, T->keys[0],
                        T->idx[0]);
     NB_HIP(ctx, hipGetLastError());
@@ -1287,7 +1400,7 @@ int nb_tree_build(nbody_ctx* ctx, const float4* posm_in) {
     }
     T->sorted = cur;
     hipLaunchKernelGGL(k_prefix, dim3(T->pf_nb), dim3(256), 0, st, T->keys[cur], n, D, ctx->cfg.leaflist_mode, T->lo, T->top,
-                       T->flags, T->blk, T->pf_nb);
+                       T->flags, T->blk, T->pf_nb, T->idx[cur], patch ? patch->multi : (const uint8_t*)nullptr);
     hipLaunchKernelGGL(k_rowscan, dim3(NCNT), dim3(256), 0, st, T->blk, T->pf_nb, T->lvl_total);
     hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(256), 0, st, T->lvl_total, T->lvl_start, NCNT);
     NB_HIP(ctx, hipGetLastError());
@@ -1319,7 +1432,6 @@ int nb_tree_build(nbody_ctx* ctx, const float4* posm_in) {
         // descend further (or, for coincident bodies, never end)
         NB_HIP(ctx, hipStreamSynchronize(st));
         T->have_tree = false;
-        nb_time_end(ctx, 2);
         return nb_fail(ctx, NBODY_ERR_CAPACITY,
                        "octree.rs variant (max_depth 0): two bodies share a level-16 cell, beyond the 16 levels reproduced");
     }
@@ -1327,6 +1439,11 @@ int nb_tree_build(nbody_ctx* ctx, const float4* posm_in) {
         hipLaunchKernelGGL(k_leaflist, dim3((n + 255) / 256), dim3(256), 0, st, T->keys[cur], T->idx[cur], posm_in, n,
                            ctx->cfg.leaflist_mode, T->flags, T->body_node, T->nodes, T->bmin, T->bmax, T->range, T->node_head,
                            (uint32_t)T->cap_nodes, mac);
+        NB_HIP(ctx, hipGetLastError());
+    }
+    if (patch) {  // the top tree's deepest nodes are the domains' own nodes
+        hipLaunchKernelGGL(k_top_patch, dim3((n + 255) / 256), dim3(256), 0, st, T->idx[cur], T->body_node, n, *patch, T->nodes,
+                           T->bmin, T->bmax, T->range, (uint32_t)T->cap_nodes);
         NB_HIP(ctx, hipGetLastError());
     }
     for (int d = D - 1; d >= 0; --d) {
@@ -1344,13 +1461,430 @@ int nb_tree_build(nbody_ctx* ctx, const float4* posm_in) {
                                ctx->cfg.leaflist_mode);
         }
     }
-    nb_time_end(ctx, 2);
     NB_HIP(ctx, hipGetLastError());
     T->have_tree = true;
     T->built = true;
     T->export_is_upload = false;
     ++T->horder_age;
-    ctx->counters.octree_nodes = total;
+    return NBODY_OK;
+}
+
+
+// ---- domain-decomposed build (no counterpart in the reference, which builds one tree on one host:
+// src/octree_maxdepth.rs:26-61) ---------------------------------------------------------------
+// The bodies are dealt to G domains, each a run of whole depth-L cells in Morton order holding about
+// n / G bodies.  Every domain builds the tree of ITS bodies with the ordinary builder (work in
+// proportion to n / G: on several GPUs, one domain each).  Below depth L a cell lies in one domain, so
+// its subtree there is the subtree of the one tree over all bodies, bit for bit; the cells above depth
+// L are rebuilt from the domains' depth-L cells (and the bodies that are alone in a larger cell) by the
+// same builder with those as its "bodies" -- the top tree, a few thousand nodes, the only part every
+// domain must hold.  The traversal then runs over the top tree with the domains' trees hung below it.
+constexpr int MAX_DOMAINS = 32;
+constexpr int DOMAIN_TOP_LEVELS_MAX = 6;
+
+struct Domains {
+    uint32_t G = 0, L = 0, cells = 0;
+    uint32_t* ckey = nullptr;        // [n] depth-L cell of each body
+    uint32_t* cell_count = nullptr;  // [cells]
+    uint8_t* cell_dom = nullptr;     // [cells]
+    uint32_t* dkey[2] = {nullptr, nullptr};  // [n] one radix pass: key = domain ...
+    uint32_t* dval[2] = {nullptr, nullptr};  // ... value = body; dval[1] ends up grouped by domain, index order kept
+    uint32_t* d_off = nullptr;       // [G + 1] first body of each domain in dval[1]
+    uint32_t* h_off = nullptr;       // pinned copy
+    float4* posm_k = nullptr;        // [n] the domains' bodies, domain after domain
+    Octree* tree[MAX_DOMAINS] = {};
+    Octree* top = nullptr;
+    uint32_t top_cap = 0, top_node_cap = 0;
+    uint32_t* n_entries = nullptr;   // device counter, and its pinned copy
+    uint32_t* h_entries = nullptr;
+    float4* e_posm = nullptr;
+    uint8_t* e_multi = nullptr;
+    QNode* e_rec = nullptr;
+    float4* e_bmin = nullptr;
+    float4* e_bmax = nullptr;
+    float* e_range = nullptr;
+    uint32_t* mark = nullptr;        // [node capacity] which domains' targets visited a node (counting traversal)
+    uint64_t mark_cap = 0;
+    unsigned long long* imported = nullptr;  // [MAX_DOMAINS + 1] device
+    uint64_t node_base[MAX_DOMAINS + 1] = {};
+    hipEvent_t ev[MAX_DOMAINS + 3][2] = {};
+    nbody_domain_stats_t stats{};
+};
+
+namespace {
+
+// The depth-L cell of every body (the reference's descent, as k_morton), and the cells' populations
+// among every `stride`-th body: a sample is all the balancing needs, and counting every body would
+// put millions of atomic additions on the few cells at the centre of a cluster (15 ms at N = 16M).
+__global__ void k_cellkey(const float4* __restrict__ posm, uint32_t n, float world, int L, uint32_t stride,
+                          uint32_t* __restrict__ ckey, uint32_t* __restrict__ cell_count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = posm[i];
+    float ext = world / 2.0f;
+    float cx = ext, cy = ext, cz = ext;
+    uint32_t key = 0;
+    for (int l = 0; l < L; ++l) {
+        ext = ext / 2.0f;
+        uint32_t ci = 0;
+        float wx = -1.0f, wy = -1.0f, wz = -1.0f;
+        if (p.x >= cx) { ci |= 4u; wx = 1.0f; }
+        if (p.y >= cy) { ci |= 2u; wy = 1.0f; }
+        if (p.z >= cz) { ci |= 1u; wz = 1.0f; }
+        key = (key << 3) | ci;
+        cx = cx + (ext * wx);
+        cy = cy + (ext * wy);
+        cz = cz + (ext * wz);
+    }
+    ckey[i] = key;
+    if (i % stride == 0) atomicAdd(&cell_count[key], 1u);
+}
+
+// One workgroup: the cells in Morton order; a cell goes to the domain its middle body (of the n counted)
+// would fall in if the bodies were dealt evenly.  Domains are runs of whole cells: their sizes differ by
+// about half a cell's bodies at most.
+__global__ __launch_bounds__(1024) void k_cell_domains(const uint32_t* __restrict__ cell_count, uint32_t cells, uint32_t n,
+                                                       uint32_t G, uint8_t* __restrict__ cell_dom) {
+    __shared__ uint32_t part[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (cells + 1023u) / 1024u, c0 = tid * per, c1 = min(cells, c0 + per);
+    uint32_t sum = 0;
+    for (uint32_t c = c0; c < c1; ++c) sum += cell_count[c];
+    part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t acc = 0;
+        for (int t = 0; t < 1024; ++t) {
+            const uint32_t v = part[t];
+            part[t] = acc;
+            acc += v;
+        }
+    }
+    __syncthreads();
+    uint32_t before = part[tid];
+    for (uint32_t c = c0; c < c1; ++c) {
+        const uint32_t cnt = cell_count[c];
+        const uint32_t d = min(G - 1u, (uint32_t)(((unsigned long long)(before + cnt / 2u) * G) / n));
+        cell_dom[c] = (uint8_t)d;
+        before += cnt;
+    }
+}
+
+// The domains' first bodies from the radix pass's digit totals (digit = domain).
+__global__ void k_domain_offsets(const uint32_t* __restrict__ row_total, uint32_t G, uint32_t* __restrict__ d_off) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (uint32_t d = 0; d < G; ++d) {
+            d_off[d] = acc;
+            acc += row_total[d];
+        }
+        d_off[G] = acc;
+    }
+}
+
+__global__ void k_body_domain(const uint32_t* __restrict__ ckey, const uint8_t* __restrict__ cell_dom, uint32_t n,
+                              uint32_t* __restrict__ dkey, uint32_t* __restrict__ dval) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    dkey[i] = cell_dom[ckey[i]];
+    dval[i] = i;
+}
+
+__global__ void k_gather_bodies(const float4* __restrict__ posm, const uint32_t* __restrict__ body, uint32_t n,
+                                float4* __restrict__ out) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) out[j] = posm[body[j]];
+}
+
+// A domain's nodes into the merged array: child indices become indices of the merged array.
+__global__ void k_rebase(const QNode* __restrict__ src, const float* __restrict__ src_range, uint32_t count, uint32_t base,
+                         QNode* __restrict__ dst, float* __restrict__ dst_range) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= count) return;
+    QNode nd = src[id];
+    if (qn_type(nd) != NBODY_NODE_LEAFBODY) nd.first += base;
+    dst[base + id] = nd;
+    dst_range[base + id] = src_range[id];
+}
+
+// The merged sorted order: a domain's sorted bodies under their indices among all bodies.
+__global__ void k_global_order(const uint64_t* __restrict__ keys_k, const uint32_t* __restrict__ idx_k,
+                               const uint32_t* __restrict__ body, uint32_t n, uint64_t* __restrict__ keys_out,
+                               uint32_t* __restrict__ idx_out) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    keys_out[r] = keys_k[r];
+    idx_out[r] = body[idx_k[r]];
+}
+
+// What a domain contributes to the top tree: its nodes at depth L, and the bodies that are alone in a
+// larger cell of its own tree (LEAFBODY nodes above depth L).  The domain's nodes above depth L hold
+// only its own share of their cells and are not used.
+__global__ void k_top_entries(const QNode* __restrict__ nodes, const float4* __restrict__ bmin, const float4* __restrict__ bmax,
+                              const float* __restrict__ range, const uint32_t* __restrict__ node_head,
+                              const uint32_t* __restrict__ idx_sorted, const float4* __restrict__ posm_k,
+                              const uint32_t* __restrict__ lvl_start, int L, uint32_t limit, uint32_t base,
+                              uint32_t* __restrict__ n_entries, uint32_t cap, float4* __restrict__ e_posm,
+                              uint8_t* __restrict__ e_multi, QNode* __restrict__ e_rec, float4* __restrict__ e_bmin,
+                              float4* __restrict__ e_bmax, float* __restrict__ e_range, uint32_t* __restrict__ err_flag) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= limit) return;
+    int d = 0;
+    while (d < L && id >= lvl_start[d + 1]) ++d;
+    QNode nd = nodes[id];
+    const bool leaf = qn_type(nd) == NBODY_NODE_LEAFBODY;
+    if (d < L && !leaf) return;
+    const uint32_t e = atomicAdd(n_entries, 1u);
+    if (e >= cap) {
+        *err_flag = 1;
+        return;
+    }
+    float4 pos = make_float4(nd.cx, nd.cy, nd.cz, nd.mass);
+    if (!leaf) {
+        pos = posm_k[idx_sorted[node_head[id]]];  // any body of the cell names it
+        nd.first += base;
+    }
+    e_posm[e] = pos;
+    e_multi[e] = leaf ? 0 : 1;
+    e_rec[e] = nd;
+    e_bmin[e] = leaf ? make_float4(nd.cx, nd.cy, nd.cz, 0.0f) : bmin[id];
+    e_bmax[e] = leaf ? make_float4(nd.cx, nd.cy, nd.cz, 0.0f) : bmax[id];
+    e_range[e] = leaf ? 0.0f : range[id];
+}
+
+// After a counting traversal: per domain, the nodes of OTHER domains' trees its targets visited (what
+// it would have to be sent if every domain sat on a GPU of its own); slot G counts the top tree's nodes
+// that any target visited.
+__global__ void k_imported(const uint32_t* __restrict__ mark, uint32_t first, uint32_t count, uint32_t owner, uint32_t G,
+                           unsigned long long* __restrict__ imported) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= count) return;
+    const uint32_t bits = mark[first + r];
+    if (!bits) return;
+    if (owner >= G) {
+        atomicAdd(&imported[G], 1ull);
+        return;
+    }
+    for (uint32_t k = 0; k < G; ++k)
+        if (k != owner && (bits >> k) & 1u) atomicAdd(&imported[k], 1ull);
+}
+
+}  // namespace
+
+namespace {
+void domain_marks(Octree* T, uint32_t** mark, const uint32_t** dom_off, uint32_t* n_dom) {
+    *mark = T->dom->mark;  // null until a counting traversal has made it
+    *dom_off = T->dom->d_off;
+    *n_dom = T->dom->G;
+}
+}  // namespace
+
+static void domains_free(Octree* T) {
+    Domains* Dm = T->dom;
+    if (!Dm) return;
+    for (Octree* t : Dm->tree) tree_free(t);
+    tree_free(Dm->top);
+    void* ptrs[] = {Dm->ckey, Dm->cell_count, Dm->cell_dom, Dm->dkey[0], Dm->dkey[1], Dm->dval[0], Dm->dval[1], Dm->d_off,
+                    Dm->posm_k, Dm->n_entries, Dm->e_posm, Dm->e_multi, Dm->e_rec, Dm->e_bmin, Dm->e_bmax, Dm->e_range,
+                    Dm->mark, Dm->imported};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (Dm->h_off) (void)hipHostFree(Dm->h_off);
+    if (Dm->h_entries) (void)hipHostFree(Dm->h_entries);
+    for (auto& pair : Dm->ev)
+        for (hipEvent_t e : pair)
+            if (e) (void)hipEventDestroy(e);
+    delete Dm;
+    T->dom = nullptr;
+}
+
+int nb_tree_set_domains(nbody_ctx* ctx, uint32_t domains, uint32_t top_levels) {
+    Octree* T = ctx->tree;
+    NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    domains_free(T);
+    T->have_tree = false;
+    T->horder = nullptr;
+    if (domains <= 1) return NBODY_OK;
+    if (domains > MAX_DOMAINS) return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_bh_set_domains: at most 32 domains");
+    if (top_levels < 1 || top_levels > DOMAIN_TOP_LEVELS_MAX || top_levels >= T->D)
+        return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_bh_set_domains: top_levels must be in [1, 6] and below max_depth");
+    if (T->octree_rs || ctx->cfg.quadrupole)
+        return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_bh_set_domains: not with max_depth 0 or with quadrupoles");
+    if (ctx->i_count != ctx->n) return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_bh_set_domains: the context must hold all bodies (no shard range)");
+    Domains* Dm = new Domains;
+    T->dom = Dm;
+    Dm->G = domains;
+    Dm->L = top_levels;
+    Dm->cells = 1u << (3 * top_levels);
+    const uint64_t n = T->n_cap;
+    auto fail = [&](int code, const char* msg) {
+        domains_free(T);
+        return nb_fail(ctx, code, msg);
+    };
+    hipError_t e = hipMalloc(&Dm->ckey, n * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&Dm->cell_count, Dm->cells * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&Dm->cell_dom, Dm->cells);
+    for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+        e = hipMalloc(&Dm->dkey[k], n * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(&Dm->dval[k], n * sizeof(uint32_t));
+    }
+    if (e == hipSuccess) e = hipMalloc(&Dm->d_off, (MAX_DOMAINS + 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipHostMalloc(&Dm->h_off, (MAX_DOMAINS + 1) * sizeof(uint32_t), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc(&Dm->posm_k, n * sizeof(float4));
+    // the top tree's entries: every depth-L cell at most once, plus lone bodies above (fewer than cells)
+    Dm->top_cap = (uint32_t)std::min<uint64_t>(2ull * Dm->cells + 1024, n + 1024);
+    Dm->top_node_cap = 2 * Dm->top_cap + 1024;
+    if (e == hipSuccess) e = hipMalloc(&Dm->n_entries, sizeof(uint32_t));
+    if (e == hipSuccess) e = hipHostMalloc(&Dm->h_entries, sizeof(uint32_t), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc(&Dm->e_posm, Dm->top_cap * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc(&Dm->e_multi, Dm->top_cap);
+    if (e == hipSuccess) e = hipMalloc(&Dm->e_rec, Dm->top_cap * sizeof(QNode));
+    if (e == hipSuccess) e = hipMalloc(&Dm->e_bmin, Dm->top_cap * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc(&Dm->e_bmax, Dm->top_cap * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc(&Dm->e_range, Dm->top_cap * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&Dm->imported, (MAX_DOMAINS + 1) * sizeof(unsigned long long));
+    for (auto& pair : Dm->ev)
+        for (hipEvent_t& ev : pair)
+            if (e == hipSuccess) e = hipEventCreate(&ev);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(NBODY_ERR_NOMEM, "nbody_bh_set_domains: out of device memory");
+    }
+    // the domains' trees: room for a third more than an even share (domains are runs of whole cells)
+    const uint64_t share = std::min<uint64_t>(n, n / domains + n / (3 * domains) + 4096);
+    for (uint32_t k = 0; k < domains; ++k) {
+        Dm->tree[k] = new Octree;
+        if (int r = tree_alloc(ctx, Dm->tree[k], share, T->D)) {
+            domains_free(T);
+            return r;
+        }
+    }
+    Dm->top = new Octree;
+    if (int r = tree_alloc(ctx, Dm->top, Dm->top_cap, top_levels)) {
+        domains_free(T);
+        return r;
+    }
+    return NBODY_OK;
+}
+
+static int domains_build(nbody_ctx* ctx, Octree* T, const float4* posm_in) {
+    Domains* Dm = T->dom;
+    hipStream_t st = ctx->stream;
+    const uint32_t n = (uint32_t)T->n_cap, G = Dm->G;
+    const int L = (int)Dm->L;
+    T->have_tree = false;
+    // 1. which body goes where
+    NB_HIP(ctx, hipEventRecord(Dm->ev[MAX_DOMAINS][0], st));
+    NB_HIP(ctx, hipMemsetAsync(Dm->cell_count, 0, Dm->cells * sizeof(uint32_t), st));
+    const uint32_t stride = std::max(1u, n / 131072u), sampled = (n + stride - 1) / stride;
+    hipLaunchKernelGGL(k_cellkey, dim3((n + 255) / 256), dim3(256), 0, st, posm_in, n, ctx->cfg.world, L, stride, Dm->ckey,
+                       Dm->cell_count);
+    hipLaunchKernelGGL(k_cell_domains, dim3(1), dim3(1024), 0, st, Dm->cell_count, Dm->cells, sampled, G, Dm->cell_dom);
+    hipLaunchKernelGGL(k_body_domain, dim3((n + 255) / 256), dim3(256), 0, st, Dm->ckey, Dm->cell_dom, n, Dm->dkey[0], Dm->dval[0]);
+    const uint32_t rs_nb = (n + RS_TILE - 1) / RS_TILE;  // (T's scan workspace is made for n bodies)
+    hipLaunchKernelGGL(k_rs_hist<uint32_t>, dim3(rs_nb), dim3(RS_THREADS), 0, st, Dm->dkey[0], n, 0, T->rs_counts, rs_nb);
+    hipLaunchKernelGGL(k_rowscan, dim3(256), dim3(256), 0, st, T->rs_counts, rs_nb, T->row_total);
+    hipLaunchKernelGGL(k_domain_offsets, dim3(1), dim3(64), 0, st, T->row_total, G, Dm->d_off);
+    hipLaunchKernelGGL(k_rs_scatter<uint32_t>, dim3(rs_nb), dim3(RS_THREADS), 0, st, Dm->dkey[0], Dm->dval[0], Dm->dkey[1],
+                       Dm->dval[1], n, 0, T->rs_counts, T->row_total, rs_nb);
+    NB_HIP(ctx, hipGetLastError());
+    NB_HIP(ctx, hipMemcpyAsync(Dm->h_off, Dm->d_off, (G + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    NB_HIP(ctx, hipMemsetAsync(Dm->n_entries, 0, sizeof(uint32_t), st));
+    NB_HIP(ctx, hipEventRecord(Dm->ev[MAX_DOMAINS][1], st));
+    NB_HIP(ctx, hipStreamSynchronize(st));
+    // 2. every domain's own tree, and what it hands to the top tree
+    Dm->node_base[0] = Dm->top_node_cap;
+    uint64_t merged = 0;
+    for (uint32_t k = 0; k < G; ++k) {
+        const uint32_t off = Dm->h_off[k], nk = Dm->h_off[k + 1] - off;
+        Octree* Tk = Dm->tree[k];
+        Dm->stats.bodies[k] = nk;
+        Dm->stats.nodes[k] = 0;
+        NB_HIP(ctx, hipEventRecord(Dm->ev[k][0], st));
+        if (nk > 0) {
+            if (nk > Tk->n_cap) {  // a domain grown past its room: new arrays, with room to spare
+                const uint32_t D = Tk->D;
+                tree_free(Tk);
+                Dm->tree[k] = Tk = new Octree;
+                if (int r = tree_alloc(ctx, Tk, (uint64_t)nk + nk / 4 + 4096, D)) return r;
+            }
+            hipLaunchKernelGGL(k_gather_bodies, dim3((nk + 255) / 256), dim3(256), 0, st, posm_in, Dm->dval[1] + off, nk,
+                               Dm->posm_k + off);
+            if (int r = build_into(ctx, Tk, Dm->posm_k + off, nk, nullptr)) return r;
+            Dm->stats.nodes[k] = Tk->n_nodes;
+        }
+        NB_HIP(ctx, hipEventRecord(Dm->ev[k][1], st));
+        Dm->node_base[k + 1] = Dm->node_base[k] + (nk ? Tk->n_nodes : 0);
+    }
+    const uint64_t total = Dm->node_base[G];
+    if (total > 0xfffffff0ull) return nb_fail(ctx, NBODY_ERR_CAPACITY, "octree needs more than 2^32 nodes");
+    if (int r = ensure_nodes(ctx, T, total)) return r;
+    NB_HIP(ctx, hipEventRecord(Dm->ev[MAX_DOMAINS + 1][0], st));
+    for (uint32_t k = 0; k < G; ++k) {
+        const uint32_t off = Dm->h_off[k], nk = Dm->h_off[k + 1] - off;
+        if (!nk) continue;
+        Octree* Tk = Dm->tree[k];
+        const uint32_t base = (uint32_t)Dm->node_base[k], cnt = (uint32_t)Tk->n_nodes;
+        hipLaunchKernelGGL(k_rebase, dim3((cnt + 255) / 256), dim3(256), 0, st, Tk->nodes, Tk->range, cnt, base, T->nodes, T->range);
+        hipLaunchKernelGGL(k_global_order, dim3((nk + 255) / 256), dim3(256), 0, st, Tk->keys[Tk->sorted], Tk->idx[Tk->sorted],
+                           Dm->dval[1] + off, nk, T->keys[0] + off, T->idx[0] + off);
+        const uint32_t limit = Tk->h_lvl_start[L + 1];
+        hipLaunchKernelGGL(k_top_entries, dim3((limit + 255) / 256), dim3(256), 0, st, Tk->nodes, Tk->bmin, Tk->bmax, Tk->range,
+                           Tk->node_head, Tk->idx[Tk->sorted], Dm->posm_k + off, Tk->lvl_start, L, limit, base, Dm->n_entries,
+                           Dm->top_cap, Dm->e_posm, Dm->e_multi, Dm->e_rec, Dm->e_bmin, Dm->e_bmax, Dm->e_range, T->err_flag);
+        merged += Tk->n_nodes - limit;  // its nodes below depth L (those at depth L and the lone bodies above reappear in the top tree)
+    }
+    NB_HIP(ctx, hipGetLastError());
+    NB_HIP(ctx, hipMemcpyAsync(Dm->h_entries, Dm->n_entries, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    NB_HIP(ctx, hipStreamSynchronize(st));
+    const uint32_t M = *Dm->h_entries;
+    if (M == 0 || M > Dm->top_cap) return nb_fail(ctx, NBODY_ERR_CAPACITY, "domain build: more top-tree entries than there is room for");
+    // 3. the top tree over those entries, its deepest nodes being the domains' own
+    const TopPatch patch{Dm->e_multi, Dm->e_rec, Dm->e_bmin, Dm->e_bmax, Dm->e_range};
+    if (int r = build_into(ctx, Dm->top, Dm->e_posm, M, &patch)) return r;
+    if (Dm->top->n_nodes > Dm->top_node_cap) return nb_fail(ctx, NBODY_ERR_CAPACITY, "domain build: the top tree outgrew its room");
+    NB_HIP(ctx, hipMemcpyAsync(T->nodes, Dm->top->nodes, Dm->top->n_nodes * sizeof(QNode), hipMemcpyDeviceToDevice, st));
+    NB_HIP(ctx, hipMemcpyAsync(T->range, Dm->top->range, Dm->top->n_nodes * sizeof(float), hipMemcpyDeviceToDevice, st));
+    NB_HIP(ctx, hipEventRecord(Dm->ev[MAX_DOMAINS + 1][1], st));
+    T->sorted = 0;
+    T->n = n;
+    T->n_nodes = total;
+    T->have_tree = true;
+    T->built = true;
+    T->export_is_upload = false;
+    ++T->horder_age;
+    Dm->stats.domains = G;
+    Dm->stats.top_levels = (uint32_t)L;
+    Dm->stats.top_entries = M;
+    Dm->stats.top_nodes = Dm->top->n_nodes;
+    Dm->stats.merged_nodes = merged + Dm->top->n_nodes;
+    return NBODY_OK;
+}
+
+int nb_tree_domain_stats(nbody_ctx* ctx, nbody_domain_stats_t* out) {
+    Octree* T = ctx->tree;
+    Domains* Dm = T->dom;
+    if (!Dm) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_bh_domain_stats: no domains set (nbody_bh_set_domains)");
+    if (!T->have_tree) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_bh_domain_stats: no tree built yet");
+    NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    auto ms = [&](int slot) {
+        float t = 0.0f;
+        return hipEventElapsedTime(&t, Dm->ev[slot][0], Dm->ev[slot][1]) == hipSuccess ? (double)t : 0.0;
+    };
+    for (uint32_t k = 0; k < Dm->G; ++k) Dm->stats.build_ms[k] = ms((int)k);
+    Dm->stats.partition_ms = ms(MAX_DOMAINS);
+    Dm->stats.merge_ms = ms(MAX_DOMAINS + 1);
+    *out = Dm->stats;
+    return NBODY_OK;
+}
+
+int nb_tree_build(nbody_ctx* ctx, const float4* posm_in) {
+    Octree* T = ctx->tree;
+    nb_time_begin(ctx, 2);
+    const int r = T->dom ? domains_build(ctx, T, posm_in) : build_into(ctx, T, posm_in, (uint32_t)T->n_cap, nullptr);
+    nb_time_end(ctx, 2);
+    if (r) return r;
+    ctx->counters.octree_nodes = T->n_nodes;
     return NBODY_OK;
 }
 
@@ -1358,6 +1892,18 @@ static int walk_launch(nbody_ctx* ctx, Octree* T, const uint32_t* order, uint32_
                        const float4* vel_in, float4* acc_out, uint32_t i_begin, int out_by_rank) {
     hipStream_t st = ctx->stream;
     if (ctx->counting) NB_HIP(ctx, hipMemsetAsync(T->walk_counters, 0, NWALK_COUNTERS * sizeof(uint64_t), st));
+    Domains* Dm = (ctx->counting && T->built) ? T->dom : nullptr;
+    if (Dm) {  // the marks of which domains' targets visit which nodes
+        if (Dm->mark_cap < T->cap_nodes) {
+            if (Dm->mark) NB_HIP(ctx, hipFree(Dm->mark));
+            Dm->mark = nullptr;
+            Dm->mark_cap = 0;
+            NB_HIP(ctx, hipMalloc(&Dm->mark, T->cap_nodes * sizeof(uint32_t)));
+            Dm->mark_cap = T->cap_nodes;
+        }
+        NB_HIP(ctx, hipMemsetAsync(Dm->mark, 0, T->n_nodes * sizeof(uint32_t), st));
+        NB_HIP(ctx, hipMemsetAsync(Dm->imported, 0, (MAX_DOMAINS + 1) * sizeof(unsigned long long), st));
+    }
     nb_time_begin(ctx, 1);
     if (ctx->cfg.law == NBODY_LAW_WGSL_BIAS)
         launch_walk<NBODY_LAW_WGSL_BIAS>(ctx, T, order, m, posm_in, vel_in, acc_out, i_begin, out_by_rank);
@@ -1381,6 +1927,19 @@ static int walk_launch(nbody_ctx* ctx, Octree* T, const uint32_t* order, uint32_
         ctx->counters.bh_aggregate_interactions = h[2];
         ctx->counters.bh_wave_node_visits = h[3];
         ctx->counters.bh_max_stack = h[4];
+        if (Dm) {
+            const uint32_t G = Dm->G;
+            for (uint32_t k = 0; k <= G; ++k) {  // slot G: the top tree
+                const uint32_t first = k < G ? (uint32_t)Dm->node_base[k] : 0u;
+                const uint32_t cnt = k < G ? (uint32_t)(Dm->node_base[k + 1] - Dm->node_base[k]) : (uint32_t)Dm->top->n_nodes;
+                if (cnt) hipLaunchKernelGGL(k_imported, dim3((cnt + 255) / 256), dim3(256), 0, st, Dm->mark, first, cnt, k, G, Dm->imported);
+            }
+            unsigned long long imp[MAX_DOMAINS + 1];
+            NB_HIP(ctx, hipMemcpyAsync(imp, Dm->imported, sizeof imp, hipMemcpyDeviceToHost, st));
+            NB_HIP(ctx, hipStreamSynchronize(st));
+            for (uint32_t k = 0; k < G; ++k) Dm->stats.imported_nodes[k] = imp[k];
+            Dm->stats.top_nodes_visited = imp[G];
+        }
         return check_err_flag(ctx, T, "traversal");
     }
     return NBODY_OK;
@@ -1432,7 +1991,7 @@ int nb_tree_walk(nbody_ctx* ctx, const float4* posm_in, const float4* vel_in, fl
             // all bodies: grouped along the Hilbert curve, the order kept over several builds
             static const bool hilbert = env_int_or("NBODY_WALK_HILBERT", 1) != 0;
             order = T->idx[T->sorted];
-            if (hilbert && T->n >= HILBERT_MIN_N) {
+            if (hilbert && T->n >= HILBERT_MIN_N && !(T->dom && ctx->counting)) {
                 if (!T->horder || T->horder_age >= HILBERT_KEEP) {
                     int r = make_hilbert_order(ctx, T);
                     if (r) return r;
@@ -1500,6 +2059,8 @@ int nb_tree_download(nbody_ctx* ctx, nbody_octree_node* host_nodes, uint64_t cap
 int nb_tree_device_nodes(nbody_ctx* ctx, void** ptr, size_t* bytes) {
     Octree* T = ctx->tree;
     if (!T->have_tree) return nb_fail(ctx, NBODY_ERR_STATE, "no octree");
+    if (T->dom && !T->export_is_upload)
+        return nb_fail(ctx, NBODY_ERR_STATE, "a domain-decomposed tree is not exported in the 96-byte layout (nbody_bh_set_domains(ctx, 0, 0) first)");
     if (T->export_cap < T->n_nodes) {
         if (T->export_is_upload) return nb_fail(ctx, NBODY_ERR_STATE, "octree export buffer lost");
         if (T->export_buf) NB_HIP(ctx, hipFree(T->export_buf));
@@ -1623,14 +2184,17 @@ int nb_tree_set_target_order(nbody_ctx* ctx, const uint32_t* host_order, uint64_
 int nb_tree_keys(nbody_ctx* ctx, uint64_t* keys, uint8_t* depth, uint32_t* order) {
     Octree* T = ctx->tree;
     if (!T->have_tree || !T->built) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_morton_keys needs a tree built by nbody_build_octree");
+    if (T->dom && depth) return nb_fail(ctx, NBODY_ERR_STATE, "leaf depths are not kept for a domain-decomposed tree (pass NULL)");
     const uint64_t n = T->n;
     std::vector<uint64_t> k(n);
     std::vector<uint32_t> id(n);
     std::vector<uint8_t> tp(n), fl(n);
     NB_HIP(ctx, hipMemcpyAsync(k.data(), T->keys[T->sorted], n * 8, hipMemcpyDeviceToHost, ctx->stream));
     NB_HIP(ctx, hipMemcpyAsync(id.data(), T->idx[T->sorted], n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    NB_HIP(ctx, hipMemcpyAsync(tp.data(), T->top, n, hipMemcpyDeviceToHost, ctx->stream));
-    NB_HIP(ctx, hipMemcpyAsync(fl.data(), T->flags, n, hipMemcpyDeviceToHost, ctx->stream));
+    if (depth) {
+        NB_HIP(ctx, hipMemcpyAsync(tp.data(), T->top, n, hipMemcpyDeviceToHost, ctx->stream));
+        NB_HIP(ctx, hipMemcpyAsync(fl.data(), T->flags, n, hipMemcpyDeviceToHost, ctx->stream));
+    }
     NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (uint64_t r = 0; r < n; ++r) {
         const uint32_t b = id[r];

@@ -227,6 +227,20 @@ class NBodySim:
         order = np.ascontiguousarray(order, dtype=np.uint32)
         self._ck(self.lib.nbody_bh_set_target_order(self.h, _ptr(order), len(order)))
 
+    def bh_set_domains(self, domains, top_levels=4):
+        """Domain-decomposed octree build (domains <= 1: off): every domain's tree from its own bodies,
+        the cells above depth top_levels rebuilt from the domains' cells.  Results do not change."""
+        self._ck(self.lib.nbody_bh_set_domains(self.h, domains, top_levels))
+
+    def bh_domain_stats(self):
+        st = _lib.NBodyDomainStats()
+        self._ck(self.lib.nbody_bh_domain_stats(self.h, C.byref(st)))
+        g = st.domains
+        out = {f: getattr(st, f) for f, _ in _lib.NBodyDomainStats._fields_ if f not in ("bodies", "nodes", "imported_nodes", "build_ms")}
+        for f in ("bodies", "nodes", "imported_nodes", "build_ms"):
+            out[f] = list(getattr(st, f))[:g]
+        return out
+
     # -- measurement ---------------------------------------------------------------------------
     def energy(self):
         k, u = C.c_double(), C.c_double()

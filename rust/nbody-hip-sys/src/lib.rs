@@ -87,6 +87,24 @@ pub struct nbody_counters_t {
     pub reserved: [u64; 6],
 }
 
+/// Sizes and times of the last domain-decomposed build (`nbody_bh_set_domains`).
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct nbody_domain_stats_t {
+    pub domains: u32,
+    pub top_levels: u32,
+    pub top_entries: u64,
+    pub top_nodes: u64,
+    pub merged_nodes: u64,
+    pub top_nodes_visited: u64,
+    pub partition_ms: f64,
+    pub merge_ms: f64,
+    pub bodies: [u64; 32],
+    pub nodes: [u64; 32],
+    pub imported_nodes: [u64; 32],
+    pub build_ms: [f64; 32],
+}
+
 #[repr(C)]
 pub struct nbody_ctx {
     _private: [u8; 0],
@@ -113,6 +131,8 @@ extern "C" {
     /// No counterpart in the reference: RCCL communicator inside the library (one process per GPU).
     pub fn nbody_comm_unique_id(id_out128: *mut c_void) -> c_int;
     pub fn nbody_comm_init(ctx: *mut nbody_ctx, unique_id128: *const c_void, rank: c_int, world: c_int) -> c_int;
+    pub fn nbody_bh_set_domains(ctx: *mut nbody_ctx, domains: u32, top_levels: u32) -> c_int;
+    pub fn nbody_bh_domain_stats(ctx: *mut nbody_ctx, out: *mut nbody_domain_stats_t) -> c_int;
     pub fn nbody_bh_set_target_order(ctx: *mut nbody_ctx, host_order: *const u32, count: u64) -> c_int;
     pub fn nbody_comm_sorted_run(n_bodies: u64, world: c_int, rank: c_int, begin: *mut u64, count: *mut u64) -> c_int;
     pub fn nbody_comm_exchange_plan(n_bodies: u64, world: c_int, begin: *const u64, count: *const u64) -> c_int;

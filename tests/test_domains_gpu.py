@@ -1,0 +1,110 @@
+"""Domain-decomposed octree build (nbody_bh_set_domains; no counterpart in the reference, which builds
+one tree on one host: src/octree_maxdepth.rs:26-61): every domain's tree from its own bodies, the cells
+above depth L rebuilt from the domains' cells.  The merged tree must be the one tree over all bodies:
+accelerations bit for bit, the same visits and interactions per traversal, the same number of nodes."""
+import numpy as np
+import pytest
+
+import nbody_amd as nb
+
+pytestmark = pytest.mark.gpu
+
+
+def _bodies(kind, n):
+    if kind == "plummer":
+        m, p, _ = nb.gen_plummer(n, seed=11)
+    else:
+        m, p = nb.gen_refcube(n, seed=11)
+        if kind == "clumps":   # a third of the bodies in three tight clumps, one of them inside a single depth-16 cell
+            rng = np.random.default_rng(5)
+            k = n // 9
+            for c, (centre, width) in enumerate((((60.0, 70.0, 80.0), 2.0), ((190.0, 60.0, 130.0), 0.05),
+                                                 ((125.0, 125.0, 125.0), 250.0 / 65536 * 0.4))):
+                base = np.array(centre, np.float32)
+                if c == 2:
+                    base = np.float32(250.0 / 65536) * np.floor(base / np.float32(250.0 / 65536)) + np.float32(250.0 / 65536 * 0.3)
+                p[c * k:(c + 1) * k, :3] = base + (rng.random((k, 3)) * width).astype(np.float32)
+    v = np.zeros((n, 4), np.float32)
+    v[:, :3] = 0.2 * (nb.gen_refcube(n, seed=12)[1][:, :3] / 125.0 - 1.0)
+    return m, p, v
+
+
+def _run(sim, steps):
+    sim.build_octree()
+    nodes = sim.counters()["octree_nodes"]
+    acc = sim.accel_bh()
+    sim.set_counting(True)
+    sim.accel_bh()
+    c = sim.counters()
+    sim.set_counting(False)
+    sim.step_bh(steps)
+    return nodes, acc, (c["bh_node_visits"], c["bh_leaf_interactions"], c["bh_aggregate_interactions"]), sim.download()
+
+
+@pytest.mark.parametrize("kind,n", [("plummer", 200003), ("refcube", 50000), ("clumps", 90000)])
+@pytest.mark.parametrize("domains,top_levels", [(2, 1), (8, 3), (5, 4), (32, 5)])
+@pytest.mark.parametrize("law", [nb.LAW_PLUMMER, nb.LAW_WGSL_BIAS])
+def test_merged_tree_is_the_one_tree(kind, n, domains, top_levels, law):
+    if law == nb.LAW_WGSL_BIAS and (kind != "plummer" or domains != 8):
+        pytest.skip("the reference's law on one configuration is enough: the tree does not depend on the law")
+    m, p, v = _bodies(kind, n)
+    with nb.NBodySim(n, law=law) as sim:
+        sim.upload(m, p, v)
+        nodes0, acc0, cnt0, state0 = _run(sim, 3)
+    with nb.NBodySim(n, law=law) as sim:
+        sim.upload(m, p, v)
+        sim.bh_set_domains(domains, top_levels)
+        nodes1, acc1, cnt1, state1 = _run(sim, 3)
+        st = sim.bh_domain_stats()
+        with pytest.raises(nb.NBodyError):
+            sim.download_octree()
+        sim.bh_set_domains(0, 0)               # and back to the one tree
+        sim.upload(m, p, v)
+        nodes2, acc2, cnt2, state2 = _run(sim, 3)
+    assert np.isfinite(acc0).all()
+    assert np.array_equal(acc0, acc1) and cnt0 == cnt1
+    for a, b in zip(state0, state1):
+        assert np.array_equal(a, b)
+    assert np.array_equal(acc0, acc2) and cnt0 == cnt2 and nodes0 == nodes2
+    assert st["domains"] == domains and st["top_levels"] == top_levels
+    assert sum(st["bodies"]) == n
+
+
+def test_domain_stats_after_a_counting_traversal():
+    n, domains = 300000, 8
+    m, p, v = _bodies("plummer", n)
+    with nb.NBodySim(n, law=nb.LAW_PLUMMER) as sim:
+        sim.upload(m, p, v)
+        sim.build_octree()
+        whole = sim.counters()["octree_nodes"]
+    with nb.NBodySim(n, law=nb.LAW_PLUMMER) as sim:
+        sim.upload(m, p, v)
+        sim.bh_set_domains(domains, 4)
+        sim.build_octree()
+        sim.set_counting(True)
+        sim.accel_bh()
+        st = sim.bh_domain_stats()
+    assert st["merged_nodes"] == whole                      # node for node the one tree
+    assert sum(st["bodies"]) == n and min(st["bodies"]) > 0
+    assert max(st["bodies"]) < 2.0 * n / domains            # runs of whole cells: even within a cell's bodies
+    assert st["top_nodes"] <= 2 * st["top_entries"] + 64 and st["top_entries"] <= 8 ** 4 + 64
+    assert 0 < st["top_nodes_visited"] <= st["top_nodes"]
+    for k in range(domains):
+        others = sum(st["nodes"]) - st["nodes"][k]
+        assert 0 < st["imported_nodes"][k] < others         # a domain needs some of the others' nodes, never all
+        assert st["build_ms"][k] > 0
+
+
+def test_domains_are_refused_where_they_do_not_apply():
+    with nb.NBodySim(1000, shard_begin=0, shard_count=500) as sim:
+        with pytest.raises(nb.NBodyError):
+            sim.bh_set_domains(4, 3)
+    with nb.NBodySim(1000, max_depth=3) as sim:
+        with pytest.raises(nb.NBodyError):
+            sim.bh_set_domains(4, 3)                          # top_levels must stay below max_depth
+        sim.bh_set_domains(4, 2)
+    with nb.NBodySim(1000) as sim:
+        with pytest.raises(nb.NBodyError):
+            sim.bh_set_domains(33, 3)
+        with pytest.raises(nb.NBodyError):
+            sim.bh_domain_stats()                             # nothing set

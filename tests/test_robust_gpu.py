@@ -33,19 +33,22 @@ def test_pile_in_one_cell_builds_and_walks_in_bounded_time(orc, mode, coincident
     targets = [(0, 64), (n_pile - 64, 128), (n - 64, 64)]
     with nb.NBodySim(n, law=nb.LAW_PLUMMER, leaflist_mode=mode) as sim:
         sim.upload(m, p)
-        sim.build_octree(); sim.sync()
-        t0 = time.time()
-        sim.build_octree(); sim.sync()
-        t_build = time.time() - t0
+        sim.build_octree(); sim.accel_bh()
+        sim.set_kernel_timing(True)
+        sim.kernel_time(build=True); sim.kernel_time(bh=True)
+        sim.build_octree()
         nodes = sim.download_octree()
         keys, depth, _ = sim.morton_keys()
-        t0 = time.time()
         acc = sim.accel_bh()
-        t_walk = time.time() - t0
+        t_build, t_walk = sim.kernel_time(build=True)[0], sim.kernel_time(bh=True)[0]
+        sim.set_kernel_timing(False)
         sim.set_counting(True)
         sim.accel_bh()
         c_all = sim.counters()
-    assert t_build < 1.0 and t_walk < 5.0, (t_build, t_walk)
+    # Measured (tools/pile_time.py): build 14.4 ms -- the cell's aggregate is a chain of 100,000 dependent f32
+    # roundings, ~0.14 us each with the cell's bodies loaded 64 at a time (50 ms with one load per step) --
+    # and traversal 10.8 ms (every body of the pile meets every member of the list); three times that.
+    assert t_build < 45.0 and t_walk < 35.0, (t_build, t_walk)
     assert np.isfinite(acc[n_pile:]).all()
     assert c_all["bh_max_stack"] <= 8 * 18
     # the pile is one LEAFLIST node with the reference's member count (literal: k - 1 prefix aggregates)

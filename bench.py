@@ -288,8 +288,12 @@ def main():
         sim = ShardedSim(be, nbodies, rank, world, bh_balance_every=args.bh_balance_every,
                          library_comm=args.comm == "library")
         sim.step_bh(2)
-        be.sim.set_counting(True)
-        be.sim.bh_forces_ranked(*sim.bh_ranges[rank])   # counting build of the traversal kernel, own targets only
+        be.sim.set_counting(True)                        # counting build of the traversal kernel, own targets only
+        if world == 1:
+            be.sim.build_octree()
+            be.sim.accel_bh()                            # (the grouping of the timed steps: targets along the Hilbert curve)
+        else:
+            be.sim.bh_forces_ranked(*sim.bh_ranges[rank])
         c = be.sim.counters()
         be.sim.set_counting(False)
         be.sim.set_kernel_timing(True)
@@ -366,6 +370,41 @@ def main():
                 "issue_roofline": issue,
                 "equivalent_allpairs_interactions_per_s": float(nbodies) * nbodies * bsteps / bdt}
 
+    def domains_leg(nbodies, domains, top_levels):
+        """The domain-decomposed octree build on this one GPU (every domain's tree from its own bodies, the
+        top of the tree rebuilt from the domains' cells): what one GPU of `domains` would spend building,
+        and how many nodes of the others' trees its targets visit -- against the one tree over all bodies."""
+        m_, p_, v_ = (masses, pos, vel) if nbodies == n else nb.gen_plummer(nbodies, seed=42)
+        res = {}
+        for label, g in (("one_tree", 0), ("domains", domains)):
+            with nb.NBodySim(nbodies, law=nb.LAW_PLUMMER) as s_:
+                s_.upload(m_, p_, v_)
+                if g:
+                    s_.bh_set_domains(g, top_levels)
+                s_.build_octree()
+                s_.accel_bh()
+                s_.set_kernel_timing(True)
+                s_.kernel_time(build=True)
+                for _ in range(3):
+                    s_.build_octree()
+                bms, _ = s_.kernel_time(build=True)
+                s_.set_kernel_timing(False)
+                s_.set_counting(True)
+                acc_ = s_.accel_bh()
+                c_ = s_.counters()
+                res[label] = (bms, acc_, c_, s_.bh_domain_stats() if g else None)
+        (b0, a0, c0, _), (b1, a1, c1, st) = res["one_tree"], res["domains"]
+        same = bool(np.array_equal(a0, a1)) and all(c0[k] == c1[k] for k in
+                                                     ("bh_node_visits", "bh_leaf_interactions", "bh_aggregate_interactions"))
+        return {"n_bodies": nbodies, "domains": domains, "top_levels": top_levels, "one_tree_build_ms": b0,
+                "per_domain_build_ms": st["build_ms"], "slowest_domain_over_one_tree": max(st["build_ms"]) / b0,
+                "partition_ms": st["partition_ms"], "merge_ms": st["merge_ms"], "bodies": st["bodies"],
+                "top_nodes": st["top_nodes"], "merged_nodes": st["merged_nodes"], "one_tree_nodes": c0["octree_nodes"],
+                "imported_nodes": st["imported_nodes"], "imported_MB_per_step": [x * 36 / 1e6 for x in st["imported_nodes"]],
+                "results_identical_to_one_tree": same,
+                "note": "logical domains on ONE GPU, built one after the other; per_domain_build_ms is each domain's own "
+                        "gather + build, i.e. what a GPU holding only that domain would spend (projected, not a multi-GPU run)"}
+
     def extra(key, fn):
         """An extra leg must not cost the headline line.  (With several ranks a failure cannot be
         contained -- the others would wait in a collective -- so there it propagates.)"""
@@ -387,6 +426,8 @@ def main():
         if n == 1 << 20:
             extra("barnes_hut_16m", lambda: bh_leg(1 << 24, 5))
             extra("barnes_hut_16m_wgsl_bias_law", lambda: bh_leg(1 << 24, 3, nb.LAW_WGSL_BIAS))
+            if world == 1:
+                extra("barnes_hut_16m_domains", lambda: domains_leg(1 << 24, 8, 5))
     if rank == 0 and args.gpus == 1 and not args.no_extras:
         try:
             out["cpu_baseline"] = cpu_baseline()

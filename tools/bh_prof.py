@@ -7,7 +7,5 @@ law = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 m, p, v = nb.gen_plummer(n, seed=42)
 with nb.NBodySim(n, law=law) as sim:
     sim.upload(m, p, v)
-    for _ in range(3):
-        sim.build_octree()
-        sim.bh_forces_ranked(0, n)     # traversal of all bodies, accelerations stay on the device
+    sim.step_bh(3)                     # build + traversal (targets grouped along the Hilbert curve) + integration, three times
     sim.sync()

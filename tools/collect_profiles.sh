@@ -23,5 +23,9 @@ for n in 1048576 16777216; do for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_bh
   timeout -s KILL 300 rocprofv3 --pmc $c -d /tmp/pmc_bh --output-format csv -- python3 $R/tools/bh_prof.py $n > /dev/null 2> $O/pmc_bh.err
   python3 $R/tools/pmc_sum.py /tmp/pmc_bh > $O/pmc_bh_${n}_$c.json
+  # ... and with the reference's own law (law id 1) in the traversal
+  rm -rf /tmp/pmc_bh
+  timeout -s KILL 300 rocprofv3 --pmc $c -d /tmp/pmc_bh --output-format csv -- python3 $R/tools/bh_prof.py $n 1 > /dev/null 2> $O/pmc_bh.err
+  python3 $R/tools/pmc_sum.py /tmp/pmc_bh > $O/pmc_bh_${n}_wgsl_bias_$c.json
 done; done
 echo done

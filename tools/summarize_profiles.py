@@ -29,11 +29,19 @@ json.dump(ap, open(os.path.join(dst, f"{out}_pmc_allpairs.json"), "w"), indent=1
 bh = {"command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes) -- python3 tools/bh_prof.py N  (3 builds + 3 traversals)",
       "note": "per-launch averages; FETCH_SIZE doubled (gfx950 correction), WRITE_SIZE as is; counter unit KB"}
 for n in (1048576, 16777216):
-    t = traffic(os.path.join(src, f"pmc_bh_{n}_FETCH_SIZE.json"), os.path.join(src, f"pmc_bh_{n}_WRITE_SIZE.json"))
-    build = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in t.items()
-                if k.startswith("k_") and not k.startswith("k_walk") and k != "k_pack_posm") / t["k_morton"]["launches"]
-    t["octree_build_bytes_per_build"] = build  # (tools/bh_prof.py builds twice per iteration: k_morton runs once per build)
-    bh[f"n_{n}"] = t
+    for suffix in ("", "_wgsl_bias"):
+        ff = os.path.join(src, f"pmc_bh_{n}{suffix}_FETCH_SIZE.json")
+        if not os.path.exists(ff):
+            continue
+        t = traffic(ff, os.path.join(src, f"pmc_bh_{n}{suffix}_WRITE_SIZE.json"))
+        # one build = every k_* launch that is not the traversal, its launch order (k_walk_order), the Hilbert
+        # grouping of its targets (k_hilbert and the 32-bit-key sort passes, made once per 16 builds), the upload or the
+        # integration of the step tools/bh_prof.py takes
+        not_build = ("k_walk", "k_pack_posm", "k_hilbert", "k_rs_hist<unsigned int>", "k_rs_scatter<unsigned int>", "k_integrate")
+        build = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in t.items()
+                    if k.startswith("k_") and not k.startswith(not_build)) / t["k_morton"]["launches"]
+        t["octree_build_bytes_per_build"] = build  # (tools/bh_prof.py builds twice per iteration: k_morton runs once per build)
+        bh[f"n_{n}{suffix}"] = t
 json.dump(bh, open(os.path.join(dst, f"{out}_pmc_bh.json"), "w"), indent=1)
 
 line = json.load(open(os.path.join(src, "bench_line.json")))

@@ -336,7 +336,10 @@ def main():
             "r*_pmc_bh.json", lambda d: kernel_entry(d[pkey], "k_walk")["hbm_bytes_per_launch"] / world)
         build_traffic, build_src = profile_traffic("r*_pmc_bh.json", lambda d: d[pkey]["octree_build_bytes_per_build"])
         visits_per_s = wave_visits / world / (wms * 1e-3) if wms > 0 else 0.0
-        issue = None
+        issue = {"bound": "issue", "unit": "wavefront node visits/s", "achieved": visits_per_s,
+                 "simd_cycles_per_visit": N_SIMDS * NOMINAL_CLOCK_MHZ * 1e6 / visits_per_s if visits_per_s > 0 else 0.0,
+                 "note": "this law's per-visit instruction sequence (six transcendentals per term) has not been timed in "
+                         "isolation, so no ceiling is quoted for it; the PLUMMER legs carry one"}
         if law_name in WALK_ISSUE_CYCLES_PER_VISIT:
             cyc = WALK_ISSUE_CYCLES_PER_VISIT[law_name]
             peak_visits = N_SIMDS * NOMINAL_CLOCK_MHZ * 1e6 / cyc

@@ -277,6 +277,21 @@ def main():
                 "kernel": "k_ap_sym" if spath == 2 else "plain", "kernel_ms": skm, "achieved_tflops": ach,
                 "frac": ach / PEAK_FP32_TFLOPS, "flop_per_interaction": fl}
 
+    def ordered_pair_leg(nbodies, steps):
+        """The ordered-pair PLUMMER kernel (what sharded contexts, small N and the no-allocation entry point
+        run) at the headline size, the pair kernel switched off for the duration of the leg."""
+        old = os.environ.get("NBODY_AP_SYM")
+        os.environ["NBODY_AP_SYM"] = "0"
+        try:
+            r = small_leg(nbodies, nb.LAW_PLUMMER, steps)
+        finally:
+            if old is None:
+                del os.environ["NBODY_AP_SYM"]
+            else:
+                os.environ["NBODY_AP_SYM"] = old
+        r["kernel"] = "k_allpairs_plummer_pk (one evaluation per ordered pair; equal masses applied once per target)"
+        return r
+
     def bh_leg(nbodies, bsteps, bh_law=None):
         """Barnes-Hut step, theta = 0.5, depth cap 16.  With several GPUs every rank holds all bodies:
         replicated octree build, traversal of this rank's run of the sorted (Morton) order,
@@ -422,6 +437,8 @@ def main():
     if not args.no_config2 and not args.no_extras and world == 1:
         extra("allpairs_n65536", lambda: {"plummer": small_leg(65536, nb.LAW_PLUMMER, 50),
                                           "wgsl_bias": small_leg(65536, nb.LAW_WGSL_BIAS, 10)})
+    if not args.no_config2 and not args.no_extras and world == 1 and args.law == "plummer":
+        extra("allpairs_ordered_pair_kernel", lambda: ordered_pair_leg(n, 2))
     if not args.no_extras and args.law == "plummer":
         extra("barnes_hut", lambda: bh_leg(n, 20))
         # the reference's traversal shader applies its acos/pow bias too (src/nbodybh.wgsl:90-101)

@@ -192,7 +192,8 @@ int nbody_integrate_ranked(nbody_ctx* ctx);
  * device).  nbody_comm_unique_id fills 128 bytes (an RCCL unique id) on ONE rank; the host hands
  * them to the other ranks by its own means (a file, MPI, torch.distributed ...).  nbody_comm_init
  * (collective: every rank calls it with the same id) attaches an RCCL communicator to the context;
- * RCCL is loaded then, from the process if it already holds one.  The ranks' contexts either have
+ * RCCL is loaded then: the librccl beside the HIP runtime this library is bound to (a process that
+ * imported PyTorch first shares PyTorch's copies of both).  The ranks' contexts either have
  * shard ranges that tile [0, n_bodies) in rank order, or all hold every body (no shard range).
  * With a communicator nbody_step_allpairs and nbody_step_bh are complete steps, nsteps of them,
  * enqueued on the context's stream with their collectives:

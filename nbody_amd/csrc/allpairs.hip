@@ -26,6 +26,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 // Two targets per packed register pair against one source: every VALU instruction of the
 // PLUMMER term is a v_pk_*_f32 with the source operand broadcast, plus two v_rsq_f32.
+// UNIFORM: every body has the same mass, which is then applied once per target when the slices are
+// summed instead of once per term here (eleven packed instructions per pair of terms instead of twelve).
+template <bool UNIFORM = false>
 __device__ __forceinline__ void interact_plummer_pk(const f2 px, const f2 py, const f2 pz, const float4 s, float eps2,
                                                     f2& ax, f2& ay, f2& az) {
     f2 dx = s.x - px, dy = s.y - py, dz = s.z - pz;
@@ -33,7 +36,7 @@ __device__ __forceinline__ void interact_plummer_pk(const f2 px, const f2 py, co
     f2 rinv;
     rinv.x = __builtin_amdgcn_rsqf(r2.x);
     rinv.y = __builtin_amdgcn_rsqf(r2.y);
-    f2 sc = (s.w * rinv) * (rinv * rinv);
+    f2 sc = UNIFORM ? rinv * (rinv * rinv) : (s.w * rinv) * (rinv * rinv);
     ax = __builtin_elementwise_fma(sc, dx, ax);
     ay = __builtin_elementwise_fma(sc, dy, ay);
     az = __builtin_elementwise_fma(sc, dz, az);
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(BLOCK) void k_allpairs(const float4* __restrict__ p
 
 // PLUMMER law with two targets per packed register pair (IPT even): same tiling, staging and
 // summation scheme as k_allpairs.
-template <int IPT, bool BIAS = false>
+template <int IPT, bool BIAS = false, bool UNIFORM = false>
 __global__ __launch_bounds__(BLOCK) void k_allpairs_plummer_pk(const float4* __restrict__ posm,
                                                                 float4* __restrict__ acc_part, int n, int i_begin,
                                                                 int i_count, int j_chunk, float eps2, int diag,
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(BLOCK) void k_allpairs_plummer_pk(const float4* __r
 #pragma unroll
                 for (int k = 0; k < H; ++k) {
                     if (BIAS) interact_bias_pk(px[k], py[k], pz[k], vx[k], vy[k], vz[k], vn[k], s, eps2, ax[k], ay[k], az[k]);
-                    else interact_plummer_pk(px[k], py[k], pz[k], s, eps2, ax[k], ay[k], az[k]);
+                    else interact_plummer_pk<UNIFORM>(px[k], py[k], pz[k], s, eps2, ax[k], ay[k], az[k]);
                 }
             }
         } else {
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(BLOCK) void k_allpairs_plummer_pk(const float4* __r
 #pragma unroll
                 for (int k = 0; k < H; ++k) {
                     if (BIAS) interact_bias_pk(px[k], py[k], pz[k], vx[k], vy[k], vz[k], vn[k], s, eps2, ax[k], ay[k], az[k]);
-                    else interact_plummer_pk(px[k], py[k], pz[k], s, eps2, ax[k], ay[k], az[k]);
+                    else interact_plummer_pk<UNIFORM>(px[k], py[k], pz[k], s, eps2, ax[k], ay[k], az[k]);
                 }
             }
         }
@@ -432,6 +435,7 @@ struct ApLaunch {
     float4* acc_part;  // [slices][i_count]
     int n, i_begin, i_count;
     float eps2;
+    float uniform_mass;  // > 0: every body has this mass (PLUMMER: applied once per target, in ap_finalize)
 };
 
 template <int LAW, int IPT>
@@ -444,8 +448,12 @@ void launch_ap(const ApLaunch& a, int slices, int j_chunk) {
 template <int IPT>
 void launch_ap_pk(const ApLaunch& a, int slices, int j_chunk) {
     dim3 grid((unsigned)((a.i_count + BLOCK * IPT - 1) / (BLOCK * IPT)), (unsigned)slices);
-    hipLaunchKernelGGL((k_allpairs_plummer_pk<IPT>), grid, dim3(BLOCK), 0, a.stream, a.posm, a.acc_part, a.n, a.i_begin,
-                       a.i_count, j_chunk, a.eps2, 0);
+    if (a.uniform_mass > 0.0f)
+        hipLaunchKernelGGL((k_allpairs_plummer_pk<IPT, false, true>), grid, dim3(BLOCK), 0, a.stream, a.posm, a.acc_part, a.n,
+                           a.i_begin, a.i_count, j_chunk, a.eps2, 0);
+    else
+        hipLaunchKernelGGL((k_allpairs_plummer_pk<IPT>), grid, dim3(BLOCK), 0, a.stream, a.posm, a.acc_part, a.n, a.i_begin,
+                           a.i_count, j_chunk, a.eps2, 0);
 }
 
 template <int IPT>
@@ -482,6 +490,8 @@ void launch_ap_ipt(const ApLaunch& a, int ipt, int slices, int j_chunk) {
 struct ApPlan {
     int ipt, slices, j_chunk;
 };
+// Whether launch_ap_ipt<PLUMMER> takes the packed kernel for this plan (which leaves a uniform mass to ap_finalize).
+bool ap_uses_packed_plummer(const ApPlan& pl) { return pl.ipt >= 2 && !env_int("NBODY_AP_NOPACK", 0); }
 ApPlan ap_plan(uint64_t n, uint64_t i_count, int num_cus, uint64_t max_slices_fit) {
     ApPlan pl;
     pl.ipt = env_int("NBODY_AP_IPT", 0);
@@ -517,7 +527,9 @@ void ap_forces_plain(const ApLaunch& a, int law, const ApPlan& pl) {
     }
 }
 void ap_finalize(const ApLaunch& a, int law, const ApPlan& pl, float G, float4* acc_out) {
-    const float g = (law == NBODY_LAW_CPU_R6) ? 0.0066743f : G;
+    float g = (law == NBODY_LAW_CPU_R6) ? 0.0066743f : G;
+    // the packed PLUMMER kernel left the (common) mass out of its terms
+    if (law == NBODY_LAW_PLUMMER && a.uniform_mass > 0.0f && ap_uses_packed_plummer(pl)) g *= a.uniform_mass;
     unsigned fb = (unsigned)((a.i_count + 255) / 256);
     hipLaunchKernelGGL(k_finalize, dim3(fb), dim3(256), 0, a.stream, a.acc_part, pl.slices, a.i_begin, a.i_count, g, acc_out);
 }
@@ -642,7 +654,8 @@ int nb_allpairs_forces(nbody_ctx* ctx, const float4* posm_in, const float4* vel_
         }
         ctx->acc_part_slices = pl.slices;
     }
-    const ApLaunch a{ctx->stream, posm_in, vel_in, ctx->acc_part, (int)ctx->n, (int)ctx->i_begin, (int)ctx->i_count, ctx->cfg.eps2};
+    const ApLaunch a{ctx->stream, posm_in, vel_in, ctx->acc_part, (int)ctx->n, (int)ctx->i_begin, (int)ctx->i_count, ctx->cfg.eps2,
+                     (ctx->uniform_mass && ctx->mass0 > 0.0f) ? ctx->mass0 : 0.0f};
     nb_time_begin(ctx, 0);
     ap_forces_plain(a, law, pl);
     nb_time_end(ctx, 0);
@@ -762,7 +775,7 @@ extern "C" int nbody_accel_allpairs_noalloc(const float* dev_posm, const float* 
     if ((uint64_t)pl.slices * n_bodies * sizeof(float4) > NOALLOC_SCRATCH_BYTES)
         return noalloc_fail(NBODY_ERR_CAPACITY, "nbody_accel_allpairs_noalloc: partial sums do not fit the fixed scratch");
     const ApLaunch a{(hipStream_t)stream, reinterpret_cast<const float4*>(dev_posm), reinterpret_cast<const float4*>(dev_vel16),
-                     part, (int)n_bodies, 0, (int)n_bodies, eps2};
+                     part, (int)n_bodies, 0, (int)n_bodies, eps2, 0.0f};  // (masses unknown here: taken per term)
     // every slice of every target is written by the force kernel before the sum reads it: nothing
     // of the previous call's contents is read, so the array needs no clearing
     (void)hipGetLastError();  // an error left behind by an earlier, unrelated call is not this call's

@@ -44,7 +44,24 @@ void* open_rccl() {
     if (const char* over = std::getenv("NBODY_RCCL_LIB")) {
         if (*over) return dlopen(over, RTLD_NOW | RTLD_LOCAL);
     }
-    // a copy already in the process first (same SONAME: the loader would hand it out anyway)
+    // The RCCL that sits beside the HIP runtime THIS library is bound to.  A process can hold two ROCm
+    // stacks -- PyTorch ships its own libamdhip64 / libhsa-runtime64 / librccl, loaded under other file
+    // names, so the loader does not merge them with the system's -- and an RCCL of the other stack talks
+    // to a HIP runtime that knows nothing of this library's device, stream and buffers ("no ROCm-capable
+    // device is detected" from ncclCommInitRank).  Whichever stack was loaded first is the one this
+    // library's own HIP calls resolve to; its RCCL is the one to use.
+    Dl_info hip{};
+    if (dladdr(reinterpret_cast<void*>(&hipGetDeviceCount), &hip) && hip.dli_fname && std::strstr(hip.dli_fname, "amdhip")) {
+        std::string dir(hip.dli_fname);
+        const size_t slash = dir.rfind('/');
+        if (slash != std::string::npos) {
+            dir.resize(slash + 1);
+            for (const char* name : {"librccl.so.1", "librccl.so"}) {
+                if (void* h = dlopen((dir + name).c_str(), RTLD_NOW | RTLD_LOCAL)) return h;
+            }
+        }
+    }
+    // otherwise a copy already in the process (same SONAME: the loader would hand it out anyway)
     for (const char* name : {"librccl.so.1", "librccl.so"}) {
         if (void* h = dlopen(name, RTLD_NOW | RTLD_NOLOAD)) return h;
     }

@@ -108,3 +108,21 @@ def test_domains_are_refused_where_they_do_not_apply():
             sim.bh_set_domains(33, 3)
         with pytest.raises(nb.NBodyError):
             sim.bh_domain_stats()                             # nothing set
+
+
+def test_domains_stay_bit_equal_over_a_long_run():
+    """A cold sphere collapses and rebounds: the domains' populations shift, bodies reach the clamp, the
+    grouping of the traversal's targets is renewed now and then -- 400 steps with and without domains end
+    in the same bits."""
+    n = 60000
+    m, p, v = nb.gen_plummer(n, seed=5)
+    out = []
+    for g in (0, 6):
+        with nb.NBodySim(n, law=nb.LAW_PLUMMER) as sim:
+            sim.upload(m, p, v)
+            if g:
+                sim.bh_set_domains(g, 3)
+            sim.step_bh(400)
+            out.append(sim.download())
+    for a, b in zip(*out):
+        assert np.isfinite(a).all() and np.array_equal(a, b)

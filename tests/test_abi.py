@@ -122,3 +122,17 @@ def test_rust_bindings_cover_the_header():
         c_val = int(re.search(name + r"\s*=\s*(-?\d+)", text).group(1))
         r_val = int(re.search(r"pub const " + name + r": [a-z0-9_]+ = (-?\d+);", rust).group(1))
         assert c_val == r_val, name
+
+
+def test_test_transport_exports_what_the_library_binds():
+    """tests/transport_standin/libshm_transport.so (test infrastructure: the collectives of several ranks
+    on one GPU) must offer every RCCL entry point nbody_amd/csrc/comm.hip looks up."""
+    path = os.path.join(ROOT, "tests", "transport_standin", "libshm_transport.so")
+    if not os.path.exists(path):
+        pytest.fail("the test transport is not built (run __graft_entry__.build())")
+    lib = C.CDLL(path)
+    src = open(os.path.join(ROOT, "nbody_amd", "csrc", "comm.hip")).read()
+    bound = sorted(set(re.findall(r'"(nccl[A-Za-z]+)"', src)))
+    assert len(bound) == 9, bound
+    for name in bound:
+        assert hasattr(lib, name), name

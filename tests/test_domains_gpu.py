@@ -126,3 +126,67 @@ def test_domains_stay_bit_equal_over_a_long_run():
             out.append(sim.download())
     for a, b in zip(*out):
         assert np.isfinite(a).all() and np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("n", [1, 2, 9, 70, 700])
+def test_fewer_bodies_than_domains_can_hold(n):
+    """Most domains are empty, the top tree has a handful of entries (or one)."""
+    m, p, v = _bodies("refcube", n)
+    with nb.NBodySim(n, law=nb.LAW_PLUMMER) as sim:
+        sim.upload(m, p, v)
+        nodes0, acc0, cnt0, state0 = _run(sim, 5)
+    with nb.NBodySim(n, law=nb.LAW_PLUMMER) as sim:
+        sim.upload(m, p, v)
+        sim.bh_set_domains(8, 3)
+        sim.build_octree()
+        st = sim.bh_domain_stats()
+        nodes1, acc1, cnt1, state1 = _run(sim, 5)
+    assert np.isfinite(acc0).all() and np.array_equal(acc0, acc1) and cnt0 == cnt1
+    for a, b in zip(state0, state1):
+        assert np.array_equal(a, b)
+    assert sum(st["bodies"]) == n and st["merged_nodes"] == nodes0
+
+
+@pytest.mark.parametrize("leaflist_mode", [0, 1])
+def test_one_domain_holds_everything(leaflist_mode):
+    """All bodies inside one depth-3 cell (and a tenth of them inside one depth-16 cell): one domain gets them
+    all, outgrows the room a domain is given at first and is given more; the others stay empty."""
+    n = 50000
+    rng = np.random.default_rng(3)
+    m = np.ones(n, np.float32)
+    p = np.zeros((n, 4), np.float32)
+    p[:, :3] = (40.0 + 20.0 * rng.random((n, 3))).astype(np.float32)       # world 250: depth-3 cells are 31.25 wide
+    cell = np.float32(250.0 / 65536)
+    p[: n // 10, :3] = (cell * np.floor(np.float32(50.0) / cell) + cell * (0.2 + 0.6 * rng.random((n // 10, 3)))).astype(np.float32)
+    p[:, 3] = m
+    v = np.zeros((n, 4), np.float32)
+    out = []
+    for g in (0, 8):
+        with nb.NBodySim(n, law=nb.LAW_PLUMMER, leaflist_mode=leaflist_mode) as sim:
+            sim.upload(m, p, v)
+            if g:
+                sim.bh_set_domains(g, 3)
+                sim.build_octree()
+                st = sim.bh_domain_stats()
+            out.append(_run(sim, 2))
+    (nodes0, acc0, cnt0, state0), (nodes1, acc1, cnt1, state1) = out
+    assert np.isfinite(acc0).all() and np.array_equal(acc0, acc1) and cnt0 == cnt1
+    for a, b in zip(state0, state1):
+        assert np.array_equal(a, b)
+    assert max(st["bodies"]) == n and st["merged_nodes"] == nodes0
+
+
+def test_a_given_target_grouping_is_kept_with_domains():
+    n = 40000
+    m, p, v = _bodies("plummer", n)
+    order = np.random.default_rng(9).permutation(n).astype(np.uint32)
+    acc = []
+    for g in (0, 4):
+        with nb.NBodySim(n, law=nb.LAW_PLUMMER) as sim:
+            sim.upload(m, p, v)
+            if g:
+                sim.bh_set_domains(g, 2)
+            sim.build_octree()
+            sim.bh_set_target_order(order)
+            acc.append(sim.accel_bh())
+    assert np.isfinite(acc[0]).all() and np.array_equal(acc[0], acc[1])

@@ -300,9 +300,30 @@ typedef struct nbody_domain_stats_t {
     uint64_t nodes[32];          /* nodes of each domain's own tree */
     uint64_t imported_nodes[32]; /* per domain: nodes of other domains' trees its targets visited */
     double build_ms[32];         /* each domain's own build (gather of its bodies + the ordinary builder) */
+    int32_t view_domain;         /* nbody_bh_set_domain_view: the domain the merged tree was assembled for, else -1 */
+    int32_t distributed;         /* 1: the last build was this rank's part of a distributed step (nbody_step_bh) */
+    uint64_t exported_nodes[32]; /* essential trees: nodes a domain hands to the others (view: every other domain's;
+                                    distributed: every rank's, this rank's own included) */
 } nbody_domain_stats_t;
 int nbody_bh_set_domains(nbody_ctx* ctx, uint32_t domains, uint32_t top_levels);
 int nbody_bh_domain_stats(nbody_ctx* ctx, nbody_domain_stats_t* out);
+/* Essential trees (no counterpart in the reference).  A domain on a GPU of its own does not need the
+ * other domains' whole trees: of each it needs the nodes its targets can reach, i.e. the children of
+ * every node that some point of its bodies' bounding box would refuse under the acceptance test of
+ * src/nbodybh.wgsl:104-106 -- decided by the exporting domain with the traversal's own thresholds and
+ * a margin far above rounding, so what is sent is a superset of what is visited and the accelerations
+ * stay those of the one tree, bit for bit.
+ *   nbody_bh_set_domain_view(ctx, d), d in [0, domains): one-GPU rehearsal.  Every later build still
+ *   makes all domains' trees, but assembles the merged tree as the GPU of domain d would hold it: its
+ *   own tree whole, of every other domain only its export.  nbody_accel_bh / nbody_step_bh then serve
+ *   the bodies of domain d ONLY (the other bodies' accelerations are meaningless: their own subtrees
+ *   are pruned); nbody_bh_domain_stats reports the exports.  d < 0 switches back.
+ *   With a communicator attached (nbody_comm_init, world == domains) nbody_step_bh does the same for
+ *   real: rank r builds the tree of domain r alone, the ranks exchange bounding boxes, exports and
+ *   top-tree entries (grouped broadcasts), every rank traverses for its own domain's bodies, and the
+ *   accelerations are exchanged domain by domain; all ranks then integrate all bodies, as in the
+ *   replicated-tree step. */
+int nbody_bh_set_domain_view(nbody_ctx* ctx, int32_t domain);
 
 /* Replaces the position readback of src/nbody_gpu_bh.rs:496-516 (and extends it to all state).
  * Any pointer may be NULL.  The pad lane of host_pos16 is written as 0. */

@@ -61,6 +61,9 @@ class NBodyDomainStats(C.Structure):
         ("nodes", C.c_uint64 * 32),
         ("imported_nodes", C.c_uint64 * 32),
         ("build_ms", C.c_double * 32),
+        ("view_domain", C.c_int32),
+        ("distributed", C.c_int32),
+        ("exported_nodes", C.c_uint64 * 32),
     ]
 
 
@@ -95,6 +98,7 @@ SYMBOLS = {
     "nbody_bh_set_target_order": (C.c_int, [_P, _P, C.c_uint64]),
     "nbody_bh_set_domains": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
     "nbody_bh_domain_stats": (C.c_int, [_P, C.POINTER(NBodyDomainStats)]),
+    "nbody_bh_set_domain_view": (C.c_int, [_P, C.c_int32]),
     "nbody_download": (C.c_int, [_P, _P, _P, _P]),
     "nbody_download_alt": (C.c_int, [_P, _P, _P, _P]),
     "nbody_sync": (C.c_int, [_P]),

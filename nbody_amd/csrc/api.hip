@@ -551,6 +551,15 @@ int nbody_bh_set_domains(nbody_ctx* ctx, uint32_t domains, uint32_t top_levels) 
     });
 }
 
+int nbody_bh_set_domain_view(nbody_ctx* ctx, int32_t domain) {
+    if (!ctx) return NBODY_ERR_INVALID;
+    return guarded(ctx, [&]() -> int {
+        int r = set_device(ctx);
+        if (r) return r;
+        return nb_tree_set_domain_view(ctx, (int)domain);
+    });
+}
+
 int nbody_bh_domain_stats(nbody_ctx* ctx, nbody_domain_stats_t* out) {
     if (!ctx || !out) return NBODY_ERR_INVALID;
     return guarded(ctx, [&]() -> int {

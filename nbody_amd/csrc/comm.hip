@@ -272,5 +272,30 @@ int nb_comm_gather_ranked(nbody_ctx* ctx) {
     return exchange_rows(ctx, ctx->acc_tmp, begin, count, equal);
 }
 
+// buf holds world parts of bytes_per_rank bytes; this rank's part (at rank * bytes_per_rank) reaches every rank.
+int nb_comm_allgather_inplace(nbody_ctx* ctx, void* buf, size_t bytes_per_rank) {
+    NbComm* C = ctx->comm;
+    unsigned char* b = static_cast<unsigned char*>(buf);
+    NB_NCCL(ctx, C, C->AllGather(b + (size_t)C->rank * bytes_per_rank, b, bytes_per_rank, ncclUint8, C->comm, ctx->stream));
+    return NBODY_OK;
+}
+
+// Several broadcasts as one group (one per rank and array of an exchange of unequal parts).  On its root an
+// item's send and recv may be the same pointer; items of zero bytes are skipped (on every rank alike).
+int nb_comm_broadcasts(nbody_ctx* ctx, const NbBroadcast* items, int count) {
+    NbComm* C = ctx->comm;
+    NB_NCCL(ctx, C, C->GroupStart());
+    for (int i = 0; i < count; ++i) {
+        if (!items[i].bytes) continue;
+        ncclResult_t r = C->Broadcast(items[i].send, items[i].recv, items[i].bytes, ncclUint8, items[i].root, C->comm, ctx->stream);
+        if (r != ncclSuccess) {
+            C->GroupEnd();
+            return nb_fail(ctx, NBODY_ERR_HIP, std::string("ncclBroadcast: ") + C->GetErrorString(r));
+        }
+    }
+    NB_NCCL(ctx, C, C->GroupEnd());
+    return NBODY_OK;
+}
+
 int nb_comm_rank(const nbody_ctx* ctx) { return ctx->comm->rank; }
 int nb_comm_world(const nbody_ctx* ctx) { return ctx->comm->world; }

@@ -114,6 +114,14 @@ int nb_exchange_plan(uint64_t n, int world, const uint64_t* begin, const uint64_
 int nb_comm_pair_path(nbody_ctx* ctx, bool fits_here, bool* use_pair);  // collective: asked once, then remembered
 bool nb_allpairs_pair_fits(nbody_ctx* ctx);
 int nb_comm_rank(const nbody_ctx* ctx);
+int nb_comm_allgather_inplace(nbody_ctx* ctx, void* buf, size_t bytes_per_rank);
+struct NbBroadcast {
+    const void* send;
+    void* recv;
+    size_t bytes;
+    int root;
+};
+int nb_comm_broadcasts(nbody_ctx* ctx, const NbBroadcast* items, int count);
 int nb_comm_world(const nbody_ctx* ctx);
 
 // octree (octree.hip)
@@ -131,5 +139,10 @@ int nb_tree_keys(nbody_ctx* ctx, uint64_t* keys, uint8_t* depth, uint32_t* order
 int nb_tree_set_target_order(nbody_ctx* ctx, const uint32_t* host_order, uint64_t count);
 int nb_tree_set_domains(nbody_ctx* ctx, uint32_t domains, uint32_t top_levels);
 int nb_tree_domain_stats(nbody_ctx* ctx, nbody_domain_stats_t* out);
+int nb_tree_set_domain_view(nbody_ctx* ctx, int domain);
+bool nb_tree_distributed(const nbody_ctx* ctx);  // domains set, a communicator attached: nbody_step_bh exchanges essential trees
+// One distributed Barnes-Hut force evaluation: this rank builds its own domain's tree, the ranks exchange
+// the parts of their trees the others' targets can reach and the accelerations; acc_body_out: all bodies.
+int nb_tree_forces_distributed(nbody_ctx* ctx, const float4* posm_in, const float4* vel_in, float4* acc_body_out);
 void nb_tree_forget_order(nbody_ctx* ctx);  // new bodies: the kept grouping of the traversal's targets no longer fits
 int nb_tree_device_nodes(nbody_ctx* ctx, void** ptr, size_t* bytes);

@@ -1482,6 +1482,21 @@ static int build_into(nbody_ctx* ctx, Octree* T, const float4* posm_in, uint32_t
 constexpr int MAX_DOMAINS = 32;
 constexpr int DOMAIN_TOP_LEVELS_MAX = 6;
 
+namespace {
+struct LetBox {
+    float4 lo, hi;
+};
+struct LetEntry {  // an entry of the top tree as it travels: what k_top_entries writes, in one record
+    float4 posm;
+    QNode rec;
+    float4 bmin, bmax;
+    float range;
+    uint32_t multi;
+    uint32_t pad[2];
+};
+static_assert(sizeof(LetEntry) == 96, "entry record layout");
+}  // namespace
+
 struct Domains {
     uint32_t G = 0, L = 0, cells = 0;
     uint32_t* ckey = nullptr;        // [n] depth-L cell of each body
@@ -1509,6 +1524,22 @@ struct Domains {
     uint64_t node_base[MAX_DOMAINS + 1] = {};
     hipEvent_t ev[MAX_DOMAINS + 3][2] = {};
     nbody_domain_stats_t stats{};
+    // essential-tree exchange: what a domain hands to the others instead of its whole tree
+    int view = -1;                    // >= 0: the merged tree is assembled as that domain's GPU would hold it
+    uint8_t* let_flags = nullptr;     // [let_cap] per node of the exporting domain's tree: exported
+    uint32_t* let_newid = nullptr;    // [let_cap] ... and its index among the exported nodes
+    uint32_t* let_blk = nullptr;      // per-tile counts of the compaction, then their scan
+    uint64_t let_cap = 0;
+    QNode* send_nodes = nullptr;      // [send_cap] the exported nodes, children's indices among themselves
+    float* send_range = nullptr;
+    uint64_t send_cap = 0;
+    LetEntry* send_entries = nullptr;    // [top_cap] this domain's entries of the top tree, as sent
+    LetEntry* recv_entries = nullptr;    // [top_cap] one other domain's, as received
+    LetBox* boxes = nullptr;          // [MAX_DOMAINS][LET_BOXES] where the domains' bodies are
+    uint32_t* let_counts = nullptr;   // [2 * MAX_DOMAINS] per domain {exported nodes, entries}, and its pinned copy
+    uint32_t* h_let_counts = nullptr;
+    float4* vel_k = nullptr;          // [n] velocities of this rank's domain, gathered like posm_k (the reference's law reads them)
+    float4* acc_grouped = nullptr;    // [n] accelerations, domain after domain in the order of dval[1]
 };
 
 namespace {
@@ -1669,10 +1700,209 @@ __global__ void k_imported(const uint32_t* __restrict__ mark, uint32_t first, ui
         if (k != owner && (bits >> k) & 1u) atomicAdd(&imported[k], 1ull);
 }
 
+// ---- essential trees --------------------------------------------------------------------------
+// A domain on a GPU of its own needs, of another domain's tree, only the nodes its targets can reach:
+// the children of every node that some target inside its bodies' bounding box could refuse.  The
+// exporting domain decides that with the traversal's own thresholds against the nearest point of the
+// box (a superset of what will be visited, by a margin far above the rounding of either side), numbers
+// the exported nodes in their breadth-first order -- children stay consecutive, since a node's children
+// are exported together or not at all -- and sends them with the child indices renumbered.  A node
+// whose children stay behind is sent with a child count of zero: nothing can follow it.
+constexpr int LET_ITEMS = 16, LET_TILE = 256 * LET_ITEMS;
+
+// Where a domain's bodies are, for the other domains' export decisions: box 0 bounds them all, the
+// others bound its bodies cell by cell at depth LET_BOX_DEPTH of its own tree (a run of cells in Morton
+// order is no box: one stray cell on the far side of a neighbouring octant would make a single box
+// swallow that octant's core).  Unused boxes are empty (nothing is near them).
+constexpr int LET_BOX_DEPTH = 2, LET_BOXES = 80;  // 1 + up to 64 cells + lone bodies above them (<= 8 + 1)
+__global__ __launch_bounds__(128) void k_let_box(const QNode* __restrict__ nodes, const float4* __restrict__ bmin,
+                                                 const float4* __restrict__ bmax, const uint32_t* __restrict__ lvl_start,
+                                                 uint32_t bodies, LetBox* __restrict__ out) {
+    __shared__ uint32_t used;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) used = 1;
+    LetBox empty;
+    empty.lo = make_float4(INFINITY, INFINITY, INFINITY, 0.0f);
+    empty.hi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.0f);
+    if (tid < LET_BOXES) out[tid] = empty;
+    __syncthreads();
+    if (!bodies) return;
+    const uint32_t limit = min(lvl_start[LET_BOX_DEPTH + 1], (uint32_t)blockDim.x);  // (<= 73 nodes down to that depth)
+    if (tid < limit) {
+        const QNode nd = nodes[tid];
+        const bool leaf = qn_type(nd) == NBODY_NODE_LEAFBODY;
+        LetBox b;
+        if (leaf) {
+            b.lo = b.hi = make_float4(nd.cx, nd.cy, nd.cz, 0.0f);
+        } else {
+            b.lo = bmin[tid];
+            b.hi = bmax[tid];
+        }
+        if (tid == 0) out[0] = b;
+        if (leaf || tid >= lvl_start[LET_BOX_DEPTH]) {
+            const uint32_t slot = atomicAdd(&used, 1u);
+            if (slot < (uint32_t)LET_BOXES) out[slot] = b;
+        }
+    }
+}
+
+// Whether a target somewhere in the box might not accept the node.  soft: what the traversal adds to
+// the squared distance before it compares (the softening under the PLUMMER law, else 0); the traversal
+// accepts where r^2 [+ soft] > r2_accept.
+__device__ __forceinline__ bool let_reach(const LetBox& b, const QNode& nd, float soft) {
+    const float dx = fmaxf(fmaxf(b.lo.x - nd.cx, nd.cx - b.hi.x), 0.0f);
+    const float dy = fmaxf(fmaxf(b.lo.y - nd.cy, nd.cy - b.hi.y), 0.0f);
+    const float dz = fmaxf(fmaxf(b.lo.z - nd.cz, nd.cz - b.hi.z), 0.0f);
+    const float d2 = dx * dx + dy * dy + dz * dz;
+    return !(d2 * 0.9999f > (nd.r2_accept - soft) * 1.0001f + soft * 1e-5f);
+}
+
+// Nodes [first_id, first_id + count) of domain `self`: the children of those that a target in some
+// other domain's boxes might not accept are flagged.
+__global__ void k_let_mark(const QNode* __restrict__ nodes, uint32_t first_id, uint32_t count, const LetBox* __restrict__ boxes,
+                           uint32_t G, uint32_t self, float soft, uint8_t* __restrict__ flags) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= count) return;
+    const QNode nd = nodes[first_id + r];
+    if (qn_type(nd) == NBODY_NODE_LEAFBODY) return;
+    const uint32_t cnt = qn_count(nd);
+    if (!cnt) return;
+    bool open = false;
+    for (uint32_t s = 0; s < G && !open; ++s) {
+        if (s == self) continue;
+        const LetBox* bs = boxes + (size_t)s * LET_BOXES;
+        if (!let_reach(bs[0], nd, soft)) continue;
+        for (int j = 1; j < LET_BOXES && !open; ++j) open = let_reach(bs[j], nd, soft);
+    }
+    if (open)
+        for (uint32_t j = 0; j < cnt; ++j) flags[nd.first + j] = 1;
+}
+
+__global__ __launch_bounds__(256) void k_let_count(const uint8_t* __restrict__ flags, uint32_t lo_id, uint32_t n_nodes,
+                                                   uint32_t* __restrict__ blk) {
+    __shared__ uint32_t wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t c = 0;
+    for (int it = 0; it < LET_ITEMS; ++it) {
+        const uint32_t id = lo_id + blockIdx.x * LET_TILE + it * 256 + tid;
+        if (id < n_nodes) c += flags[id] ? 1u : 0u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if (lane == 0) wsum[wave] = c;
+    __syncthreads();
+    if (tid == 0) blk[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// blk holds the exclusive scan of the tiles' counts: every exported node's index among the exported, in id order.
+__global__ __launch_bounds__(256) void k_let_number(const uint8_t* __restrict__ flags, uint32_t lo_id, uint32_t n_nodes,
+                                                    const uint32_t* __restrict__ blk, uint32_t* __restrict__ newid) {
+    __shared__ uint32_t wsum[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t run = blk[blockIdx.x];
+    for (int it = 0; it < LET_ITEMS; ++it) {
+        const uint32_t id = lo_id + blockIdx.x * LET_TILE + it * 256 + tid;
+        const bool keep = id < n_nodes && flags[id];
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) wsum[it & 1][wave] = (uint32_t)__popcll(m);
+        __syncthreads();  // the other half of wsum is what the previous round may still be reading
+        uint32_t off = run;
+        for (int w = 0; w < wave; ++w) off += wsum[it & 1][w];
+        off += (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (keep) newid[id] = off;
+        run += wsum[it & 1][0] + wsum[it & 1][1] + wsum[it & 1][2] + wsum[it & 1][3];
+    }
+}
+
+// A record as it is sent: children's index among the exported nodes, or no children at all.
+__device__ __forceinline__ QNode let_record(QNode nd, const uint8_t* __restrict__ flags, const uint32_t* __restrict__ newid) {
+    if (qn_type(nd) != NBODY_NODE_LEAFBODY) {
+        if (qn_count(nd) && flags[nd.first]) {
+            nd.first = newid[nd.first];
+        } else {
+            nd.first = 0;
+            nd.count_type = qn_pack(0, qn_type(nd));
+        }
+    }
+    return nd;
+}
+
+__global__ void k_let_pack(const QNode* __restrict__ nodes, const float* __restrict__ range, const uint8_t* __restrict__ flags,
+                           const uint32_t* __restrict__ newid, uint32_t lo_id, uint32_t n_nodes, QNode* __restrict__ out_nodes,
+                           float* __restrict__ out_range, uint32_t cap) {
+    const uint32_t id = lo_id + blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_nodes || !flags[id]) return;
+    const uint32_t o = newid[id];
+    if (o >= cap) return;
+    out_nodes[o] = let_record(nodes[id], flags, newid);
+    out_range[o] = range[id];
+}
+
+// k_top_entries into travelling records.  flags / newid given: child indices as exported; null: the
+// domain's own numbering (for the GPU that holds the whole domain).
+__global__ void k_let_entries(const QNode* __restrict__ nodes, const float4* __restrict__ bmin, const float4* __restrict__ bmax,
+                              const float* __restrict__ range, const uint32_t* __restrict__ node_head,
+                              const uint32_t* __restrict__ idx_sorted, const float4* __restrict__ posm_k,
+                              const uint32_t* __restrict__ lvl_start, int L, uint32_t limit, const uint8_t* __restrict__ flags,
+                              const uint32_t* __restrict__ newid, uint32_t* __restrict__ n_entries, uint32_t cap,
+                              LetEntry* __restrict__ out, uint32_t* __restrict__ err_flag) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= limit) return;
+    int d = 0;
+    while (d < L && id >= lvl_start[d + 1]) ++d;
+    QNode nd = nodes[id];
+    const bool leaf = qn_type(nd) == NBODY_NODE_LEAFBODY;
+    if (d < L && !leaf) return;
+    const uint32_t e = atomicAdd(n_entries, 1u);
+    if (e >= cap) {
+        *err_flag = 1;
+        return;
+    }
+    LetEntry E;
+    E.posm = leaf ? make_float4(nd.cx, nd.cy, nd.cz, nd.mass) : posm_k[idx_sorted[node_head[id]]];  // any body of the cell names it
+    E.rec = flags ? let_record(nd, flags, newid) : nd;
+    E.bmin = leaf ? make_float4(nd.cx, nd.cy, nd.cz, 0.0f) : bmin[id];
+    E.bmax = leaf ? make_float4(nd.cx, nd.cy, nd.cz, 0.0f) : bmax[id];
+    E.range = leaf ? 0.0f : range[id];
+    E.multi = leaf ? 0u : 1u;
+    E.pad[0] = E.pad[1] = 0u;
+    out[e] = E;
+}
+
+// Received (or own) entries into the arrays the top tree is built from, child indices moved to where the
+// sender's nodes were put.
+__global__ void k_let_entries_unpack(const LetEntry* __restrict__ in, uint32_t m, uint32_t base, uint32_t e0,
+                                     float4* __restrict__ e_posm, uint8_t* __restrict__ e_multi, QNode* __restrict__ e_rec,
+                                     float4* __restrict__ e_bmin, float4* __restrict__ e_bmax, float* __restrict__ e_range) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const LetEntry E = in[i];
+    QNode nd = E.rec;
+    if (qn_type(nd) != NBODY_NODE_LEAFBODY && qn_count(nd)) nd.first += base;
+    e_posm[e0 + i] = E.posm;
+    e_multi[e0 + i] = (uint8_t)E.multi;
+    e_rec[e0 + i] = nd;
+    e_bmin[e0 + i] = E.bmin;
+    e_bmax[e0 + i] = E.bmax;
+    e_range[e0 + i] = E.range;
+}
+
+// Exported nodes where they were received (arr + base): child indices become indices of arr.
+__global__ void k_let_settle(QNode* arr, uint32_t base, uint32_t count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    QNode nd = arr[base + i];
+    if (qn_type(nd) != NBODY_NODE_LEAFBODY && qn_count(nd)) {
+        nd.first += base;
+        arr[base + i] = nd;
+    }
+}
+
 }  // namespace
 
 namespace {
 void domain_marks(Octree* T, uint32_t** mark, const uint32_t** dom_off, uint32_t* n_dom) {
+    if (T->dom->view >= 0) return;  // (a merged tree assembled for one domain: no marks)
     *mark = T->dom->mark;  // null until a counting traversal has made it
     *dom_off = T->dom->d_off;
     *n_dom = T->dom->G;
@@ -1686,11 +1916,13 @@ static void domains_free(Octree* T) {
     tree_free(Dm->top);
     void* ptrs[] = {Dm->ckey, Dm->cell_count, Dm->cell_dom, Dm->dkey[0], Dm->dkey[1], Dm->dval[0], Dm->dval[1], Dm->d_off,
                     Dm->posm_k, Dm->n_entries, Dm->e_posm, Dm->e_multi, Dm->e_rec, Dm->e_bmin, Dm->e_bmax, Dm->e_range,
-                    Dm->mark, Dm->imported};
+                    Dm->mark, Dm->imported, Dm->let_flags, Dm->let_newid, Dm->let_blk, Dm->send_nodes, Dm->send_range,
+                    Dm->send_entries, Dm->recv_entries, Dm->boxes, Dm->let_counts, Dm->vel_k, Dm->acc_grouped};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (Dm->h_off) (void)hipHostFree(Dm->h_off);
     if (Dm->h_entries) (void)hipHostFree(Dm->h_entries);
+    if (Dm->h_let_counts) (void)hipHostFree(Dm->h_let_counts);
     for (auto& pair : Dm->ev)
         for (hipEvent_t e : pair)
             if (e) (void)hipEventDestroy(e);
@@ -1743,6 +1975,11 @@ int nb_tree_set_domains(nbody_ctx* ctx, uint32_t domains, uint32_t top_levels) {
     if (e == hipSuccess) e = hipMalloc(&Dm->e_bmax, Dm->top_cap * sizeof(float4));
     if (e == hipSuccess) e = hipMalloc(&Dm->e_range, Dm->top_cap * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&Dm->imported, (MAX_DOMAINS + 1) * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(&Dm->send_entries, Dm->top_cap * sizeof(LetEntry));
+    if (e == hipSuccess) e = hipMalloc(&Dm->recv_entries, Dm->top_cap * sizeof(LetEntry));
+    if (e == hipSuccess) e = hipMalloc(&Dm->boxes, (size_t)MAX_DOMAINS * LET_BOXES * sizeof(LetBox));
+    if (e == hipSuccess) e = hipMalloc(&Dm->let_counts, 2 * MAX_DOMAINS * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipHostMalloc(&Dm->h_let_counts, 2 * MAX_DOMAINS * sizeof(uint32_t), hipHostMallocDefault);
     for (auto& pair : Dm->ev)
         for (hipEvent_t& ev : pair)
             if (e == hipSuccess) e = hipEventCreate(&ev);
@@ -1767,13 +2004,12 @@ int nb_tree_set_domains(nbody_ctx* ctx, uint32_t domains, uint32_t top_levels) {
     return NBODY_OK;
 }
 
-static int domains_build(nbody_ctx* ctx, Octree* T, const float4* posm_in) {
+// 1. which body goes where (ends with the domains' first bodies on the host)
+static int domains_partition(nbody_ctx* ctx, Octree* T, const float4* posm_in) {
     Domains* Dm = T->dom;
     hipStream_t st = ctx->stream;
     const uint32_t n = (uint32_t)T->n_cap, G = Dm->G;
     const int L = (int)Dm->L;
-    T->have_tree = false;
-    // 1. which body goes where
     NB_HIP(ctx, hipEventRecord(Dm->ev[MAX_DOMAINS][0], st));
     NB_HIP(ctx, hipMemsetAsync(Dm->cell_count, 0, Dm->cells * sizeof(uint32_t), st));
     const uint32_t stride = std::max(1u, n / 131072u), sampled = (n + stride - 1) / stride;
@@ -1792,29 +2028,62 @@ static int domains_build(nbody_ctx* ctx, Octree* T, const float4* posm_in) {
     NB_HIP(ctx, hipMemsetAsync(Dm->n_entries, 0, sizeof(uint32_t), st));
     NB_HIP(ctx, hipEventRecord(Dm->ev[MAX_DOMAINS][1], st));
     NB_HIP(ctx, hipStreamSynchronize(st));
+    return NBODY_OK;
+}
+
+// 2. domain k's own tree, from its own bodies
+static int domain_build_one(nbody_ctx* ctx, Octree* T, uint32_t k, const float4* posm_in) {
+    Domains* Dm = T->dom;
+    hipStream_t st = ctx->stream;
+    const uint32_t off = Dm->h_off[k], nk = Dm->h_off[k + 1] - off;
+    Octree* Tk = Dm->tree[k];
+    Dm->stats.bodies[k] = nk;
+    Dm->stats.nodes[k] = 0;
+    NB_HIP(ctx, hipEventRecord(Dm->ev[k][0], st));
+    if (nk > 0) {
+        if (nk > Tk->n_cap) {  // a domain grown past its room: new arrays, with room to spare
+            const uint32_t D = Tk->D;
+            tree_free(Tk);
+            Dm->tree[k] = Tk = new Octree;
+            if (int r = tree_alloc(ctx, Tk, (uint64_t)nk + nk / 4 + 4096, D)) return r;
+        }
+        hipLaunchKernelGGL(k_gather_bodies, dim3((nk + 255) / 256), dim3(256), 0, st, posm_in, Dm->dval[1] + off, nk,
+                           Dm->posm_k + off);
+        if (int r = build_into(ctx, Tk, Dm->posm_k + off, nk, nullptr)) return r;
+        Dm->stats.nodes[k] = Tk->n_nodes;
+    }
+    NB_HIP(ctx, hipEventRecord(Dm->ev[k][1], st));
+    return NBODY_OK;
+}
+
+// 3. the top tree over the M entries in Dm->e_*, its deepest nodes being the domains' own; into the merged array
+static int domains_top(nbody_ctx* ctx, Octree* T, uint32_t M) {
+    Domains* Dm = T->dom;
+    hipStream_t st = ctx->stream;
+    if (M == 0 || M > Dm->top_cap) return nb_fail(ctx, NBODY_ERR_CAPACITY, "domain build: more top-tree entries than there is room for");
+    const TopPatch patch{Dm->e_multi, Dm->e_rec, Dm->e_bmin, Dm->e_bmax, Dm->e_range};
+    if (int r = build_into(ctx, Dm->top, Dm->e_posm, M, &patch)) return r;
+    if (Dm->top->n_nodes > Dm->top_node_cap) return nb_fail(ctx, NBODY_ERR_CAPACITY, "domain build: the top tree outgrew its room");
+    NB_HIP(ctx, hipMemcpyAsync(T->nodes, Dm->top->nodes, Dm->top->n_nodes * sizeof(QNode), hipMemcpyDeviceToDevice, st));
+    NB_HIP(ctx, hipMemcpyAsync(T->range, Dm->top->range, Dm->top->n_nodes * sizeof(float), hipMemcpyDeviceToDevice, st));
+    Dm->stats.top_entries = M;
+    Dm->stats.top_nodes = Dm->top->n_nodes;
+    return NBODY_OK;
+}
+
+static int domains_build(nbody_ctx* ctx, Octree* T, const float4* posm_in) {
+    Domains* Dm = T->dom;
+    hipStream_t st = ctx->stream;
+    const uint32_t n = (uint32_t)T->n_cap, G = Dm->G;
+    const int L = (int)Dm->L;
+    T->have_tree = false;
+    if (int r = domains_partition(ctx, T, posm_in)) return r;
     // 2. every domain's own tree, and what it hands to the top tree
     Dm->node_base[0] = Dm->top_node_cap;
     uint64_t merged = 0;
     for (uint32_t k = 0; k < G; ++k) {
-        const uint32_t off = Dm->h_off[k], nk = Dm->h_off[k + 1] - off;
-        Octree* Tk = Dm->tree[k];
-        Dm->stats.bodies[k] = nk;
-        Dm->stats.nodes[k] = 0;
-        NB_HIP(ctx, hipEventRecord(Dm->ev[k][0], st));
-        if (nk > 0) {
-            if (nk > Tk->n_cap) {  // a domain grown past its room: new arrays, with room to spare
-                const uint32_t D = Tk->D;
-                tree_free(Tk);
-                Dm->tree[k] = Tk = new Octree;
-                if (int r = tree_alloc(ctx, Tk, (uint64_t)nk + nk / 4 + 4096, D)) return r;
-            }
-            hipLaunchKernelGGL(k_gather_bodies, dim3((nk + 255) / 256), dim3(256), 0, st, posm_in, Dm->dval[1] + off, nk,
-                               Dm->posm_k + off);
-            if (int r = build_into(ctx, Tk, Dm->posm_k + off, nk, nullptr)) return r;
-            Dm->stats.nodes[k] = Tk->n_nodes;
-        }
-        NB_HIP(ctx, hipEventRecord(Dm->ev[k][1], st));
-        Dm->node_base[k + 1] = Dm->node_base[k] + (nk ? Tk->n_nodes : 0);
+        if (int r = domain_build_one(ctx, T, k, posm_in)) return r;
+        Dm->node_base[k + 1] = Dm->node_base[k] + Dm->stats.nodes[k];
     }
     const uint64_t total = Dm->node_base[G];
     if (total > 0xfffffff0ull) return nb_fail(ctx, NBODY_ERR_CAPACITY, "octree needs more than 2^32 nodes");
@@ -1837,14 +2106,7 @@ static int domains_build(nbody_ctx* ctx, Octree* T, const float4* posm_in) {
     NB_HIP(ctx, hipGetLastError());
     NB_HIP(ctx, hipMemcpyAsync(Dm->h_entries, Dm->n_entries, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     NB_HIP(ctx, hipStreamSynchronize(st));
-    const uint32_t M = *Dm->h_entries;
-    if (M == 0 || M > Dm->top_cap) return nb_fail(ctx, NBODY_ERR_CAPACITY, "domain build: more top-tree entries than there is room for");
-    // 3. the top tree over those entries, its deepest nodes being the domains' own
-    const TopPatch patch{Dm->e_multi, Dm->e_rec, Dm->e_bmin, Dm->e_bmax, Dm->e_range};
-    if (int r = build_into(ctx, Dm->top, Dm->e_posm, M, &patch)) return r;
-    if (Dm->top->n_nodes > Dm->top_node_cap) return nb_fail(ctx, NBODY_ERR_CAPACITY, "domain build: the top tree outgrew its room");
-    NB_HIP(ctx, hipMemcpyAsync(T->nodes, Dm->top->nodes, Dm->top->n_nodes * sizeof(QNode), hipMemcpyDeviceToDevice, st));
-    NB_HIP(ctx, hipMemcpyAsync(T->range, Dm->top->range, Dm->top->n_nodes * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (int r = domains_top(ctx, T, *Dm->h_entries)) return r;
     NB_HIP(ctx, hipEventRecord(Dm->ev[MAX_DOMAINS + 1][1], st));
     T->sorted = 0;
     T->n = n;
@@ -1855,9 +2117,189 @@ static int domains_build(nbody_ctx* ctx, Octree* T, const float4* posm_in) {
     ++T->horder_age;
     Dm->stats.domains = G;
     Dm->stats.top_levels = (uint32_t)L;
-    Dm->stats.top_entries = M;
-    Dm->stats.top_nodes = Dm->top->n_nodes;
     Dm->stats.merged_nodes = merged + Dm->top->n_nodes;
+    Dm->stats.view_domain = -1;
+    for (uint32_t k = 0; k < MAX_DOMAINS; ++k) Dm->stats.exported_nodes[k] = 0;
+    return NBODY_OK;
+}
+
+// ---- essential trees: host side ----------------------------------------------------------------
+static int let_reserve(nbody_ctx* ctx, Domains* Dm, uint64_t nodes) {
+    if (nodes <= Dm->let_cap) return NBODY_OK;
+    NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    void** arrays[] = {(void**)&Dm->let_flags, (void**)&Dm->let_newid, (void**)&Dm->let_blk, (void**)&Dm->send_nodes, (void**)&Dm->send_range};
+    for (void** a : arrays) {
+        if (*a) (void)hipFree(*a);
+        *a = nullptr;
+    }
+    Dm->let_cap = Dm->send_cap = 0;
+    const uint64_t cap = nodes + nodes / 4 + 1024;
+    NB_HIP(ctx, hipMalloc(&Dm->let_flags, cap));
+    NB_HIP(ctx, hipMalloc(&Dm->let_newid, cap * sizeof(uint32_t)));
+    NB_HIP(ctx, hipMalloc(&Dm->let_blk, ((cap + LET_TILE - 1) / LET_TILE + 1) * sizeof(uint32_t)));
+    NB_HIP(ctx, hipMalloc(&Dm->send_nodes, cap * sizeof(QNode)));
+    NB_HIP(ctx, hipMalloc(&Dm->send_range, cap * sizeof(float)));
+    Dm->let_cap = Dm->send_cap = cap;
+    return NBODY_OK;
+}
+
+// Domain k's entries of the top tree into `out`, their number into *counter (device).  exported: child
+// indices as of the last let_export of this domain; else the domain's own numbering.
+static int let_entries(nbody_ctx* ctx, Octree* T, uint32_t k, bool exported, LetEntry* out, uint32_t* counter) {
+    Domains* Dm = T->dom;
+    Octree* Tk = Dm->tree[k];
+    hipStream_t st = ctx->stream;
+    const uint32_t off = Dm->h_off[k], limit = Tk->h_lvl_start[Dm->L + 1];
+    NB_HIP(ctx, hipMemsetAsync(counter, 0, sizeof(uint32_t), st));
+    hipLaunchKernelGGL(k_let_entries, dim3((limit + 255) / 256), dim3(256), 0, st, Tk->nodes, Tk->bmin, Tk->bmax, Tk->range,
+                       Tk->node_head, Tk->idx[Tk->sorted], Dm->posm_k + off, Tk->lvl_start, (int)Dm->L, limit,
+                       exported ? Dm->let_flags : (const uint8_t*)nullptr, exported ? Dm->let_newid : (const uint32_t*)nullptr,
+                       counter, Dm->top_cap, out, T->err_flag);
+    NB_HIP(ctx, hipGetLastError());
+    return NBODY_OK;
+}
+
+// What domain k (its tree built, Dm->boxes filled) hands to the others: nodes into Dm->send_nodes /
+// send_range, entries into Dm->send_entries, their numbers into Dm->let_counts[2k], [2k + 1] (device).
+static int let_export(nbody_ctx* ctx, Octree* T, uint32_t k) {
+    Domains* Dm = T->dom;
+    Octree* Tk = Dm->tree[k];
+    hipStream_t st = ctx->stream;
+    uint32_t* counts = Dm->let_counts + 2 * k;
+    NB_HIP(ctx, hipMemsetAsync(counts, 0, 2 * sizeof(uint32_t), st));
+    if (Dm->h_off[k + 1] == Dm->h_off[k]) return NBODY_OK;
+    const uint32_t n_nodes = (uint32_t)Tk->n_nodes, mark0 = Tk->h_lvl_start[Dm->L], lo_id = Tk->h_lvl_start[Dm->L + 1];
+    if (int r = let_reserve(ctx, Dm, n_nodes)) return r;
+    NB_HIP(ctx, hipMemsetAsync(Dm->let_flags, 0, n_nodes, st));
+    const float soft = ctx->cfg.law == NBODY_LAW_PLUMMER ? ctx->cfg.eps2 : 0.0f;
+    if (n_nodes > mark0)
+        hipLaunchKernelGGL(k_let_mark, dim3((n_nodes - mark0 + 255) / 256), dim3(256), 0, st, Tk->nodes, mark0, n_nodes - mark0,
+                           Dm->boxes, Dm->G, k, soft, Dm->let_flags);
+    if (n_nodes > lo_id) {
+        const uint32_t c = n_nodes - lo_id, nb = (c + LET_TILE - 1) / LET_TILE;
+        hipLaunchKernelGGL(k_let_count, dim3(nb), dim3(256), 0, st, Dm->let_flags, lo_id, n_nodes, Dm->let_blk);
+        hipLaunchKernelGGL(k_rowscan, dim3(1), dim3(256), 0, st, Dm->let_blk, nb, counts);
+        hipLaunchKernelGGL(k_let_number, dim3(nb), dim3(256), 0, st, Dm->let_flags, lo_id, n_nodes, Dm->let_blk, Dm->let_newid);
+        hipLaunchKernelGGL(k_let_pack, dim3((c + 255) / 256), dim3(256), 0, st, Tk->nodes, Tk->range, Dm->let_flags, Dm->let_newid,
+                           lo_id, n_nodes, Dm->send_nodes, Dm->send_range, (uint32_t)Dm->send_cap);
+    }
+    NB_HIP(ctx, hipGetLastError());
+    return let_entries(ctx, T, k, true, Dm->send_entries, counts + 1);
+}
+
+static int let_box(nbody_ctx* ctx, Octree* T, uint32_t k) {
+    Domains* Dm = T->dom;
+    Octree* Tk = Dm->tree[k];
+    hipLaunchKernelGGL(k_let_box, dim3(1), dim3(128), 0, ctx->stream, Tk->nodes, Tk->bmin, Tk->bmax, Tk->lvl_start,
+                       Dm->h_off[k + 1] - Dm->h_off[k], Dm->boxes + (size_t)k * LET_BOXES);
+    NB_HIP(ctx, hipGetLastError());
+    return NBODY_OK;
+}
+
+// `count` nodes that lie at T->nodes + base (as sent) become part of the merged array; the sender's m
+// entries in `entries` join the top tree's at e0.
+static int let_settle(nbody_ctx* ctx, Octree* T, uint32_t base, uint32_t count, const LetEntry* entries, uint32_t m, uint32_t e0) {
+    Domains* Dm = T->dom;
+    hipStream_t st = ctx->stream;
+    if (count) hipLaunchKernelGGL(k_let_settle, dim3((count + 255) / 256), dim3(256), 0, st, T->nodes, base, count);
+    if (m)
+        hipLaunchKernelGGL(k_let_entries_unpack, dim3((m + 255) / 256), dim3(256), 0, st, entries, m, base, e0, Dm->e_posm,
+                           Dm->e_multi, Dm->e_rec, Dm->e_bmin, Dm->e_bmax, Dm->e_range);
+    NB_HIP(ctx, hipGetLastError());
+    return NBODY_OK;
+}
+
+// The whole tree of domain k (this GPU's own) into the merged array at base, its entries at e0; *m_out: how many.
+static int let_own(nbody_ctx* ctx, Octree* T, uint32_t k, uint32_t base, uint32_t e0, uint32_t* m_out) {
+    Domains* Dm = T->dom;
+    Octree* Tk = Dm->tree[k];
+    hipStream_t st = ctx->stream;
+    const uint32_t cnt = (uint32_t)Tk->n_nodes;
+    hipLaunchKernelGGL(k_rebase, dim3((cnt + 255) / 256), dim3(256), 0, st, Tk->nodes, Tk->range, cnt, base, T->nodes, T->range);
+    uint32_t* counter = Dm->let_counts + 2 * k + 1;
+    if (int r = let_entries(ctx, T, k, false, Dm->send_entries, counter)) return r;
+    NB_HIP(ctx, hipMemcpyAsync(Dm->h_let_counts + 2 * k + 1, counter, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    NB_HIP(ctx, hipStreamSynchronize(st));
+    const uint32_t m = Dm->h_let_counts[2 * k + 1];
+    if (e0 + (uint64_t)m > Dm->top_cap) return nb_fail(ctx, NBODY_ERR_CAPACITY, "domain build: more top-tree entries than there is room for");
+    *m_out = m;
+    return let_settle(ctx, T, base, 0, Dm->send_entries, m, e0);
+}
+
+// The merged tree as the GPU of domain `view` would hold it, on one GPU: all domains' trees are built here,
+// but the others' reach the merged array only through what they would send.  Only the targets of domain
+// `view` are served by it.
+static int domains_build_view(nbody_ctx* ctx, Octree* T, const float4* posm_in) {
+    Domains* Dm = T->dom;
+    hipStream_t st = ctx->stream;
+    const uint32_t n = (uint32_t)T->n_cap, G = Dm->G, view = (uint32_t)Dm->view;
+    T->have_tree = false;
+    if (int r = domains_partition(ctx, T, posm_in)) return r;
+    uint64_t bound = Dm->top_node_cap;
+    for (uint32_t k = 0; k < G; ++k) {
+        if (int r = domain_build_one(ctx, T, k, posm_in)) return r;
+        if (int r = let_box(ctx, T, k)) return r;
+        bound += Dm->stats.nodes[k];
+    }
+    if (bound > 0xfffffff0ull) return nb_fail(ctx, NBODY_ERR_CAPACITY, "octree needs more than 2^32 nodes");
+    if (int r = ensure_nodes(ctx, T, bound)) return r;
+    NB_HIP(ctx, hipEventRecord(Dm->ev[MAX_DOMAINS + 1][0], st));
+    uint32_t base = Dm->top_node_cap, e0 = 0;
+    for (uint32_t k = 0; k < G; ++k) {
+        const uint32_t off = Dm->h_off[k], nk = Dm->h_off[k + 1] - off;
+        Dm->node_base[k] = base;
+        Dm->stats.exported_nodes[k] = 0;
+        if (!nk) continue;
+        Octree* Tk = Dm->tree[k];
+        hipLaunchKernelGGL(k_global_order, dim3((nk + 255) / 256), dim3(256), 0, st, Tk->keys[Tk->sorted], Tk->idx[Tk->sorted],
+                           Dm->dval[1] + off, nk, T->keys[0] + off, T->idx[0] + off);
+        if (k == view) {
+            uint32_t m = 0;
+            if (int r = let_own(ctx, T, k, base, e0, &m)) return r;
+            base += (uint32_t)Tk->n_nodes;
+            e0 += m;
+            continue;
+        }
+        if (int r = let_export(ctx, T, k)) return r;
+        NB_HIP(ctx, hipMemcpyAsync(Dm->h_let_counts + 2 * k, Dm->let_counts + 2 * k, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        NB_HIP(ctx, hipStreamSynchronize(st));
+        const uint32_t c = Dm->h_let_counts[2 * k], m = Dm->h_let_counts[2 * k + 1];
+        if (c > Tk->n_nodes || e0 + (uint64_t)m > Dm->top_cap) return nb_fail(ctx, NBODY_ERR_CAPACITY, "domain build: export beyond its room");
+        if (c) {
+            NB_HIP(ctx, hipMemcpyAsync(T->nodes + base, Dm->send_nodes, (size_t)c * sizeof(QNode), hipMemcpyDeviceToDevice, st));
+            NB_HIP(ctx, hipMemcpyAsync(T->range + base, Dm->send_range, (size_t)c * sizeof(float), hipMemcpyDeviceToDevice, st));
+        }
+        if (int r = let_settle(ctx, T, base, c, Dm->send_entries, m, e0)) return r;
+        NB_HIP(ctx, hipStreamSynchronize(st));  // (the send buffers are reused by the next domain)
+        Dm->stats.exported_nodes[k] = c;
+        base += c;
+        e0 += m;
+    }
+    Dm->node_base[G] = base;
+    if (int r = domains_top(ctx, T, e0)) return r;
+    NB_HIP(ctx, hipEventRecord(Dm->ev[MAX_DOMAINS + 1][1], st));
+    T->sorted = 0;
+    T->n = n;
+    T->n_nodes = base;
+    T->have_tree = true;
+    T->built = true;
+    T->export_is_upload = false;
+    ++T->horder_age;
+    Dm->stats.domains = G;
+    Dm->stats.top_levels = Dm->L;
+    Dm->stats.merged_nodes = base - Dm->top_node_cap + Dm->top->n_nodes;
+    Dm->stats.view_domain = (int32_t)view;
+    return NBODY_OK;
+}
+
+int nb_tree_set_domain_view(nbody_ctx* ctx, int domain) {
+    Octree* T = ctx->tree;
+    Domains* Dm = T->dom;
+    if (!Dm) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_bh_set_domain_view: no domains set (nbody_bh_set_domains)");
+    if (domain >= (int)Dm->G) return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_bh_set_domain_view: no such domain");
+    NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    Dm->view = domain < 0 ? -1 : domain;
+    T->have_tree = false;
     return NBODY_OK;
 }
 
@@ -1881,7 +2323,8 @@ int nb_tree_domain_stats(nbody_ctx* ctx, nbody_domain_stats_t* out) {
 int nb_tree_build(nbody_ctx* ctx, const float4* posm_in) {
     Octree* T = ctx->tree;
     nb_time_begin(ctx, 2);
-    const int r = T->dom ? domains_build(ctx, T, posm_in) : build_into(ctx, T, posm_in, (uint32_t)T->n_cap, nullptr);
+    const int r = !T->dom ? build_into(ctx, T, posm_in, (uint32_t)T->n_cap, nullptr)
+                  : T->dom->view >= 0 ? domains_build_view(ctx, T, posm_in) : domains_build(ctx, T, posm_in);
     nb_time_end(ctx, 2);
     if (r) return r;
     ctx->counters.octree_nodes = T->n_nodes;
@@ -1892,7 +2335,7 @@ static int walk_launch(nbody_ctx* ctx, Octree* T, const uint32_t* order, uint32_
                        const float4* vel_in, float4* acc_out, uint32_t i_begin, int out_by_rank) {
     hipStream_t st = ctx->stream;
     if (ctx->counting) NB_HIP(ctx, hipMemsetAsync(T->walk_counters, 0, NWALK_COUNTERS * sizeof(uint64_t), st));
-    Domains* Dm = (ctx->counting && T->built) ? T->dom : nullptr;
+    Domains* Dm = (ctx->counting && T->built && T->dom && T->dom->view < 0) ? T->dom : nullptr;
     if (Dm) {  // the marks of which domains' targets visit which nodes
         if (Dm->mark_cap < T->cap_nodes) {
             if (Dm->mark) NB_HIP(ctx, hipFree(Dm->mark));

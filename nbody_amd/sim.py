@@ -211,9 +211,9 @@ class NBodySim:
             raise ValueError("octree nodes must be 96-byte records")
         self._ck(self.lib.nbody_upload_octree(self.h, _ptr(nodes), len(nodes)))
 
-    def morton_keys(self):
+    def morton_keys(self, with_depth=True):
         keys = np.empty(self.n, np.uint64)
-        depth = np.empty(self.n, np.uint8)
+        depth = np.empty(self.n, np.uint8) if with_depth else None  # (not kept for a domain-decomposed tree)
         order = np.empty(self.n, np.uint32)
         self._ck(self.lib.nbody_morton_keys(self.h, _ptr(keys), _ptr(depth), _ptr(order)))
         return keys, depth, order
@@ -232,12 +232,19 @@ class NBodySim:
         the cells above depth top_levels rebuilt from the domains' cells.  Results do not change."""
         self._ck(self.lib.nbody_bh_set_domains(self.h, domains, top_levels))
 
+    def bh_set_domain_view(self, domain):
+        """One-GPU rehearsal of the essential-tree exchange: later builds assemble the merged tree as the GPU
+        of `domain` would hold it (its own tree whole, of the others what they would send); only that domain's
+        bodies are served by it.  domain < 0: off."""
+        self._ck(self.lib.nbody_bh_set_domain_view(self.h, domain))
+
     def bh_domain_stats(self):
         st = _lib.NBodyDomainStats()
         self._ck(self.lib.nbody_bh_domain_stats(self.h, C.byref(st)))
         g = st.domains
-        out = {f: getattr(st, f) for f, _ in _lib.NBodyDomainStats._fields_ if f not in ("bodies", "nodes", "imported_nodes", "build_ms")}
-        for f in ("bodies", "nodes", "imported_nodes", "build_ms"):
+        per_domain = ("bodies", "nodes", "imported_nodes", "build_ms", "exported_nodes")
+        out = {f: getattr(st, f) for f, _ in _lib.NBodyDomainStats._fields_ if f not in per_domain}
+        for f in per_domain:
             out[f] = list(getattr(st, f))[:g]
         return out
 

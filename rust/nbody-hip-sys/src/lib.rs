@@ -103,6 +103,9 @@ pub struct nbody_domain_stats_t {
     pub nodes: [u64; 32],
     pub imported_nodes: [u64; 32],
     pub build_ms: [f64; 32],
+    pub view_domain: i32,
+    pub distributed: i32,
+    pub exported_nodes: [u64; 32],
 }
 
 #[repr(C)]
@@ -133,6 +136,7 @@ extern "C" {
     pub fn nbody_comm_init(ctx: *mut nbody_ctx, unique_id128: *const c_void, rank: c_int, world: c_int) -> c_int;
     pub fn nbody_bh_set_domains(ctx: *mut nbody_ctx, domains: u32, top_levels: u32) -> c_int;
     pub fn nbody_bh_domain_stats(ctx: *mut nbody_ctx, out: *mut nbody_domain_stats_t) -> c_int;
+    pub fn nbody_bh_set_domain_view(ctx: *mut nbody_ctx, domain: i32) -> c_int;
     pub fn nbody_bh_set_target_order(ctx: *mut nbody_ctx, host_order: *const u32, count: u64) -> c_int;
     pub fn nbody_comm_sorted_run(n_bodies: u64, world: c_int, rank: c_int, begin: *mut u64, count: *mut u64) -> c_int;
     pub fn nbody_comm_exchange_plan(n_bodies: u64, world: c_int, begin: *const u64, count: *const u64) -> c_int;

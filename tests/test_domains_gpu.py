@@ -190,3 +190,47 @@ def test_a_given_target_grouping_is_kept_with_domains():
             sim.bh_set_target_order(order)
             acc.append(sim.accel_bh())
     assert np.isfinite(acc[0]).all() and np.array_equal(acc[0], acc[1])
+
+
+def _domain_bodies(sim, st):
+    """Body indices of every domain: the merged sorted order, cut at the domains' populations."""
+    _, _, order = sim.morton_keys(with_depth=False)
+    cuts = np.concatenate(([0], np.cumsum(st["bodies"]))).astype(np.int64)
+    return [order[cuts[k]:cuts[k + 1]] for k in range(st["domains"])]
+
+
+@pytest.mark.parametrize("kind,n,domains,top_levels,law", [
+    ("plummer", 200003, 8, 3, nb.LAW_PLUMMER), ("plummer", 60000, 8, 4, nb.LAW_WGSL_BIAS),
+    ("refcube", 50000, 5, 2, nb.LAW_PLUMMER), ("clumps", 90000, 8, 3, nb.LAW_PLUMMER),
+    ("clumps", 90000, 3, 1, nb.LAW_WGSL_BIAS), ("refcube", 300, 8, 3, nb.LAW_PLUMMER)])
+def test_essential_trees_serve_their_domain(kind, n, domains, top_levels, law):
+    """The merged tree as ONE domain's GPU would hold it -- its own tree whole, of the others only what
+    they would send (nbody_bh_set_domain_view) -- gives that domain's bodies the one tree's accelerations
+    bit for bit, with the same visits and interactions, from fewer nodes."""
+    m, p, v = _bodies(kind, n)
+    with nb.NBodySim(n, law=law) as sim:
+        sim.upload(m, p, v)
+        sim.build_octree()
+        acc0 = sim.accel_bh()
+    assert np.isfinite(acc0).all()
+    with nb.NBodySim(n, law=law) as sim:
+        sim.upload(m, p, v)
+        sim.bh_set_domains(domains, top_levels)
+        sim.build_octree()
+        whole = sim.bh_domain_stats()
+        for d in range(domains):
+            sim.bh_set_domain_view(d)
+            sim.build_octree()
+            st = sim.bh_domain_stats()
+            mine = _domain_bodies(sim, st)[d]
+            acc = sim.accel_bh()
+            assert st["view_domain"] == d and st["bodies"] == whole["bodies"]
+            assert np.array_equal(acc[mine], acc0[mine]), d
+            assert st["exported_nodes"][d] == 0
+            for k in range(domains):
+                assert st["exported_nodes"][k] <= st["nodes"][k]
+            if n >= 50000:
+                assert st["merged_nodes"] < whole["merged_nodes"]
+        sim.bh_set_domain_view(-1)
+        sim.build_octree()
+        assert np.array_equal(sim.accel_bh(), acc0)

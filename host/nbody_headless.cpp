@@ -16,7 +16,10 @@
 // positions, velocities and accelerations, each f32[n][4].
 // --ranks R runs R processes, one per GPU (device = rank mod --devices, default R), that exchange
 // inside the library (nbody_comm_init): the all-pairs modes split the targets into R index ranges,
-// the Barnes-Hut mode keeps all bodies on every rank and splits the traversal.  Rank 0 makes the
+// the Barnes-Hut mode keeps all bodies on every rank and splits the traversal (with --domains L, L = the
+// depth of the cells the bodies are dealt by: every rank builds the octree of its own domain of bodies
+// only, and the ranks exchange the parts of their trees the others can reach; with one rank, --domains L
+// builds the tree as 8 domains on the one GPU).  Rank 0 makes the
 // communicator's id and leaves it in a file for the others; rank 0 reports.  The process started
 // by the user only supervises: every rank is a child forked before anything touches the GPU, and
 // when one of them fails the others are ended and the id file removed.
@@ -35,7 +38,7 @@
 namespace {
 
 struct Options {
-    int ranks = 1, devices = 0;
+    int ranks = 1, devices = 0, domains = 0;
     bool force_comm = false;
     std::string mode = "gpu", law, dataset = "refcube", dump, state;
     uint64_t n = 250;  // N_BODIES, src/nbody_gpu.rs:14
@@ -104,6 +107,8 @@ int run_rank(const Options& o, int rank, const std::string& id_path) {
         if ((rc = nbody_comm_init(ctx, id, rank, o.ranks))) return die(ctx, "nbody_comm_init", rc);
     }
     if ((rc = nbody_upload(ctx, masses.data(), pos.data(), nullptr, nullptr))) return die(ctx, "nbody_upload", rc);
+    if (o.domains > 0 && (rc = nbody_bh_set_domains(ctx, o.ranks > 1 ? (uint32_t)o.ranks : 8u, (uint32_t)o.domains)))
+        return die(ctx, "nbody_bh_set_domains", rc);
     std::FILE* out = nullptr;
     uint32_t dumped = 0;
     if (rank == 0 && !o.dump.empty()) {
@@ -134,6 +139,15 @@ int run_rank(const Options& o, int rank, const std::string& id_path) {
         std::printf("%s: n=%llu ranks=%d frames=%d  %.3f ms/frame  %.1f frames/s  octree nodes (last) %llu  all-pairs path %llu\n",
                     o.mode.c_str(), (unsigned long long)n, o.ranks, o.frames, 1e3 * s / o.frames, o.frames / s,
                     (unsigned long long)c.octree_nodes, (unsigned long long)c.allpairs_path);
+    if (o.domains > 0 && rank == 0) {
+        nbody_domain_stats_t st;
+        if ((rc = nbody_bh_domain_stats(ctx, &st))) return die(ctx, "nbody_bh_domain_stats", rc);
+        unsigned long long received = 0;
+        for (uint32_t k = 0; k < st.domains; ++k) received += k == (uint32_t)rank ? 0 : st.exported_nodes[k];
+        std::printf("domains: %u of depth-%u cells, %s; rank 0: own tree %llu nodes, received %llu nodes, top tree %llu nodes, merged %llu\n",
+                    st.domains, st.top_levels, st.distributed ? "distributed (one per rank)" : "on one GPU",
+                    (unsigned long long)st.nodes[0], received, (unsigned long long)st.top_nodes, (unsigned long long)st.merged_nodes);
+    }
     if (out) {
         std::fseek(out, 8, SEEK_SET);
         std::fwrite(&dumped, sizeof dumped, 1, out);
@@ -173,11 +187,12 @@ int main(int argc, char** argv) {
         else if (a == "--state") o.state = next();
         else if (a == "--ranks") o.ranks = std::atoi(next());
         else if (a == "--devices") o.devices = std::atoi(next());
+        else if (a == "--domains") o.domains = std::atoi(next());
         else if (a == "--comm") o.force_comm = true;  // a communicator even with one rank
         else {
             std::fprintf(stderr,
                          "usage: %s [--mode cpu|gpu|bh] [--law cpu_r6|wgsl_bias|plummer] [--dataset refcube|plummer] [--n N] "
-                         "[--frames F] [--report R] [--seed S] [--dump FILE] [--state FILE] [--ranks R] [--devices D] [--comm]\n",
+                         "[--frames F] [--report R] [--seed S] [--dump FILE] [--state FILE] [--ranks R] [--devices D] [--comm] [--domains L]\n",
                          argv[0]);
             return 2;
         }
@@ -189,6 +204,7 @@ int main(int argc, char** argv) {
     }
     if (o.dataset != "refcube" && o.dataset != "plummer") { std::fprintf(stderr, "--dataset must be refcube or plummer\n"); return 2; }
     if (o.ranks < 1 || (uint64_t)o.ranks > o.n) { std::fprintf(stderr, "--ranks must be in [1, n]\n"); return 2; }
+    if (o.domains && o.mode != "bh") { std::fprintf(stderr, "--domains goes with --mode bh\n"); return 2; }
     if (o.frames < 1) { std::fprintf(stderr, "--frames must be at least 1\n"); return 2; }
     if (o.devices <= 0) o.devices = o.ranks;
     const char* transport = std::getenv("NBODY_RCCL_LIB");

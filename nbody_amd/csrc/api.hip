@@ -399,6 +399,20 @@ int nbody_step_bh(nbody_ctx* ctx, int nsteps) {
         if (r) return r;
         ctx->pending_forces = 0;
         for (int s = 0; s < nsteps; ++s) {
+            if (ctx->comm && nb_tree_distributed(ctx)) {
+                // domains: this rank builds its own domain's tree, essential trees and accelerations are exchanged
+                if (!ctx->acc_body && hipMalloc(&ctx->acc_body, ctx->n * sizeof(float4)) != hipSuccess) {
+                    ctx->acc_body = nullptr;
+                    (void)hipGetLastError();
+                    return nb_fail(ctx, NBODY_ERR_NOMEM, "accelerations in body order: out of device memory");
+                }
+                r = nb_tree_forces_distributed(ctx, ctx->posm[ctx->cur], ctx->vel[ctx->cur], ctx->acc_body);
+                if (r) return r;
+                r = nb_integrate_clamped(ctx, ctx->acc_body);
+                if (r) return r;
+                ctx->counters.steps_bh += 1;
+                continue;
+            }
             r = nb_tree_build(ctx, ctx->posm[ctx->cur]);
             if (r) return r;
             if (ctx->comm) {

@@ -2119,6 +2119,7 @@ static int domains_build(nbody_ctx* ctx, Octree* T, const float4* posm_in) {
     Dm->stats.top_levels = (uint32_t)L;
     Dm->stats.merged_nodes = merged + Dm->top->n_nodes;
     Dm->stats.view_domain = -1;
+    Dm->stats.distributed = 0;
     for (uint32_t k = 0; k < MAX_DOMAINS; ++k) Dm->stats.exported_nodes[k] = 0;
     return NBODY_OK;
 }
@@ -2289,6 +2290,115 @@ static int domains_build_view(nbody_ctx* ctx, Octree* T, const float4* posm_in) 
     Dm->stats.top_levels = Dm->L;
     Dm->stats.merged_nodes = base - Dm->top_node_cap + Dm->top->n_nodes;
     Dm->stats.view_domain = (int32_t)view;
+    Dm->stats.distributed = 0;
+    return NBODY_OK;
+}
+
+static int walk_launch(nbody_ctx* ctx, Octree* T, const uint32_t* order, uint32_t m, const float4* posm_in,
+                       const float4* vel_in, float4* acc_out, uint32_t i_begin, int out_by_rank);
+
+bool nb_tree_distributed(const nbody_ctx* ctx) { return ctx->comm && ctx->tree && ctx->tree->dom; }
+
+// One Barnes-Hut force evaluation by as many ranks as there are domains (one GPU each), every rank holding
+// all bodies' state.  All ranks deal the bodies to the domains alike (the partition is a function of the
+// positions); rank r builds the tree of domain r alone, tells the others where its bodies are (boxes), is
+// told where theirs are, and exports what their targets can reach of its tree; after one exchange of the
+// counts, every rank's nodes, ranges and top-tree entries travel as one group of broadcasts, straight to
+// their places in the receivers' merged arrays.  Each rank then builds the (small) top tree, traverses for
+// the bodies of its own domain, and the accelerations are exchanged domain by domain.
+int nb_tree_forces_distributed(nbody_ctx* ctx, const float4* posm_in, const float4* vel_in, float4* acc_body_out) {
+    Octree* T = ctx->tree;
+    Domains* Dm = T->dom;
+    hipStream_t st = ctx->stream;
+    const uint32_t n = (uint32_t)T->n_cap, G = Dm->G, self = (uint32_t)nb_comm_rank(ctx);
+    if ((uint32_t)nb_comm_world(ctx) != G)
+        return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_step_bh: with a communicator there must be as many domains as ranks (nbody_bh_set_domains)");
+    if (Dm->view >= 0) return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_step_bh: nbody_bh_set_domain_view is a one-GPU rehearsal; switch it off for a distributed step");
+    T->have_tree = false;
+    if (!Dm->acc_grouped) NB_HIP(ctx, hipMalloc(&Dm->acc_grouped, (size_t)n * sizeof(float4)));
+    const bool need_vel = ctx->cfg.law == NBODY_LAW_WGSL_BIAS;
+    if (need_vel && !Dm->vel_k) NB_HIP(ctx, hipMalloc(&Dm->vel_k, (size_t)n * sizeof(float4)));
+    nb_time_begin(ctx, 2);
+    if (int r = domains_partition(ctx, T, posm_in)) return r;
+    for (uint32_t k = 0; k < G; ++k) {
+        Dm->stats.bodies[k] = Dm->h_off[k + 1] - Dm->h_off[k];
+        Dm->stats.nodes[k] = 0;
+    }
+    const uint32_t off = Dm->h_off[self], nk = Dm->h_off[self + 1] - off;
+    if (int r = domain_build_one(ctx, T, self, posm_in)) return r;
+    Octree* Ts = Dm->tree[self];
+    // where everybody's bodies are, what everybody exports
+    if (int r = let_box(ctx, T, self)) return r;
+    if (int r = nb_comm_allgather_inplace(ctx, Dm->boxes, (size_t)LET_BOXES * sizeof(LetBox))) return r;
+    if (int r = let_export(ctx, T, self)) return r;
+    if (int r = nb_comm_allgather_inplace(ctx, Dm->let_counts, 2 * sizeof(uint32_t))) return r;
+    NB_HIP(ctx, hipMemcpyAsync(Dm->h_let_counts, Dm->let_counts, 2 * G * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    NB_HIP(ctx, hipStreamSynchronize(st));
+    uint64_t base[MAX_DOMAINS + 1], e0[MAX_DOMAINS + 1];
+    base[0] = Dm->top_node_cap;
+    e0[0] = 0;
+    for (uint32_t k = 0; k < G; ++k) {
+        const uint32_t c = Dm->h_let_counts[2 * k], m = Dm->h_let_counts[2 * k + 1];
+        base[k + 1] = base[k] + (k == self ? (nk ? Ts->n_nodes : 0) : c);
+        e0[k + 1] = e0[k] + m;
+        Dm->node_base[k] = base[k];
+        Dm->stats.exported_nodes[k] = c;
+    }
+    Dm->node_base[G] = base[G];
+    if (base[G] > 0xfffffff0ull) return nb_fail(ctx, NBODY_ERR_CAPACITY, "octree needs more than 2^32 nodes");
+    if (e0[G] == 0 || e0[G] > Dm->top_cap) return nb_fail(ctx, NBODY_ERR_CAPACITY, "domain build: more top-tree entries than there is room for");
+    if (Dm->h_let_counts[2 * self] > Dm->send_cap && nk) return nb_fail(ctx, NBODY_ERR_CAPACITY, "domain build: export beyond its room");
+    if (int r = ensure_nodes(ctx, T, base[G])) return r;
+    std::vector<NbBroadcast> items;
+    for (uint32_t k = 0; k < G; ++k) {
+        const size_t c = Dm->h_let_counts[2 * k], m = Dm->h_let_counts[2 * k + 1];
+        const bool mine = k == self;
+        items.push_back({Dm->send_nodes, mine ? (void*)Dm->send_nodes : (void*)(T->nodes + base[k]), c * sizeof(QNode), (int)k});
+        items.push_back({Dm->send_range, mine ? (void*)Dm->send_range : (void*)(T->range + base[k]), c * sizeof(float), (int)k});
+        items.push_back({Dm->send_entries, mine ? (void*)Dm->send_entries : (void*)(Dm->recv_entries + e0[k]), m * sizeof(LetEntry), (int)k});
+    }
+    if (int r = nb_comm_broadcasts(ctx, items.data(), (int)items.size())) return r;
+    for (uint32_t k = 0; k < G; ++k) {
+        if (k == self) continue;
+        if (int r = let_settle(ctx, T, (uint32_t)base[k], Dm->h_let_counts[2 * k], Dm->recv_entries + e0[k], Dm->h_let_counts[2 * k + 1],
+                               (uint32_t)e0[k]))
+            return r;
+    }
+    if (nk) {  // (after the broadcasts have read the send buffers: the entries are made again, in the tree's own numbering)
+        uint32_t m = 0;
+        const uint32_t sent = Dm->h_let_counts[2 * self + 1];
+        if (int r = let_own(ctx, T, self, (uint32_t)base[self], (uint32_t)e0[self], &m)) return r;
+        if (m != sent) return nb_fail(ctx, NBODY_ERR_STATE, "domain build: a domain's entries changed between export and use");
+    }
+    if (int r = domains_top(ctx, T, (uint32_t)e0[G])) return r;
+    if (int r = check_err_flag(ctx, T, "distributed octree build")) return r;  // (the host has just waited for the top tree's level sizes anyway)
+    nb_time_end(ctx, 2);
+    Dm->stats.domains = G;
+    Dm->stats.top_levels = Dm->L;
+    Dm->stats.merged_nodes = base[G] - Dm->top_node_cap + Dm->top->n_nodes;
+    Dm->stats.view_domain = -1;
+    Dm->stats.distributed = 1;
+    ctx->counters.octree_nodes = base[G];
+    // this rank's targets: the bodies of its domain, in the sorted order of its own tree
+    if (nk) {
+        if (need_vel) hipLaunchKernelGGL(k_gather_bodies, dim3((nk + 255) / 256), dim3(256), 0, st, vel_in, Dm->dval[1] + off, nk, Dm->vel_k + off);
+        T->n = n;
+        T->n_nodes = base[G];
+        T->have_tree = true;
+        T->built = false;  // (a merged array for this rank's targets only: no keys, no order of all bodies)
+        const int r = walk_launch(ctx, T, Ts->idx[Ts->sorted], nk, Dm->posm_k + off, need_vel ? Dm->vel_k + off : nullptr,
+                                  Dm->acc_grouped + off, 0u, 0);
+        T->have_tree = false;
+        if (r) return r;
+    }
+    items.clear();
+    for (uint32_t k = 0; k < G; ++k) {
+        float4* part = Dm->acc_grouped + Dm->h_off[k];
+        items.push_back({part, part, (size_t)(Dm->h_off[k + 1] - Dm->h_off[k]) * sizeof(float4), (int)k});
+    }
+    if (int r = nb_comm_broadcasts(ctx, items.data(), (int)items.size())) return r;
+    hipLaunchKernelGGL(k_unrank, dim3((n + 255) / 256), dim3(256), 0, st, Dm->dval[1], Dm->acc_grouped, n, acc_body_out);
+    NB_HIP(ctx, hipGetLastError());
     return NBODY_OK;
 }
 
@@ -2307,11 +2417,13 @@ int nb_tree_domain_stats(nbody_ctx* ctx, nbody_domain_stats_t* out) {
     Octree* T = ctx->tree;
     Domains* Dm = T->dom;
     if (!Dm) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_bh_domain_stats: no domains set (nbody_bh_set_domains)");
-    if (!T->have_tree) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_bh_domain_stats: no tree built yet");
+    if (!T->have_tree && !Dm->stats.distributed) return nb_fail(ctx, NBODY_ERR_STATE, "nbody_bh_domain_stats: no tree built yet");
     NB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     auto ms = [&](int slot) {
         float t = 0.0f;
-        return hipEventElapsedTime(&t, Dm->ev[slot][0], Dm->ev[slot][1]) == hipSuccess ? (double)t : 0.0;
+        if (hipEventElapsedTime(&t, Dm->ev[slot][0], Dm->ev[slot][1]) == hipSuccess) return (double)t;
+        (void)hipGetLastError();  // (events of a part that did not run in the last build, e.g. another rank's domain)
+        return 0.0;
     };
     for (uint32_t k = 0; k < Dm->G; ++k) Dm->stats.build_ms[k] = ms((int)k);
     Dm->stats.partition_ms = ms(MAX_DOMAINS);

@@ -86,6 +86,29 @@ def test_barnes_hut_with_fewer_wavefronts_than_ranks(tmp_path):
     assert np.array_equal(one, many)
 
 
+@pytest.mark.parametrize("ranks,n,law,dataset,top_levels", [
+    (8, 100037, "plummer", "plummer", 3), (8, 60000, "wgsl_bias", "plummer", 4), (2, 30011, "wgsl_bias", "refcube", 1),
+    (5, 50000, "plummer", "refcube", 2), (8, 300, "plummer", "refcube", 3)])
+def test_barnes_hut_domains_exchange_essential_trees(tmp_path, ranks, n, law, dataset, top_levels):
+    """--domains: every rank builds the octree of ITS domain of bodies only; bounding boxes, exported nodes
+    and top-tree entries are exchanged (grouped broadcasts of unequal parts), every rank traverses for its
+    own domain, the accelerations are exchanged domain by domain.  Rank 0's state is the one-rank,
+    one-tree run's, bit for bit (300 bodies over 8 ranks: some domains hold a handful of bodies)."""
+    args = ["--mode", "bh", "--law", law, "--dataset", dataset, "--n", str(n), "--frames", "3", "--seed", "7"]
+    one, _ = run(tmp_path, "one", 1, args)
+    many, out = run(tmp_path, f"d{ranks}", ranks, args + ["--domains", str(top_levels)])
+    assert f"domains: {ranks} of depth-{top_levels} cells, distributed" in out
+    assert np.isfinite(one).all() and np.abs(one[2]).max() > 0
+    assert np.array_equal(one, many)
+
+
+def test_one_rank_with_domains_is_the_one_tree(tmp_path):
+    args = ["--mode", "bh", "--n", "40000", "--frames", "3", "--seed", "4"]
+    one, _ = run(tmp_path, "one", 1, args)
+    dom, _ = run(tmp_path, "dom", 1, args + ["--domains", "3"])
+    assert np.array_equal(one, dom)
+
+
 @pytest.mark.parametrize("ranks,n", [(3, 5003), (8, 5003), (4, 4096)])
 def test_allpairs_target_shards_wgsl_law(tmp_path, ranks, n):
     """The reference's law, targets split by index range: unequal shards (grouped broadcasts) and

@@ -304,6 +304,7 @@ typedef struct nbody_domain_stats_t {
     int32_t distributed;         /* 1: the last build was this rank's part of a distributed step (nbody_step_bh) */
     uint64_t exported_nodes[32]; /* essential trees: nodes a domain hands to the others (view: every other domain's;
                                     distributed: every rank's, this rank's own included) */
+    double export_ms[32];        /* choosing, numbering and packing them (the exports made by THIS process) */
 } nbody_domain_stats_t;
 int nbody_bh_set_domains(nbody_ctx* ctx, uint32_t domains, uint32_t top_levels);
 int nbody_bh_domain_stats(nbody_ctx* ctx, nbody_domain_stats_t* out);

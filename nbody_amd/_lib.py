@@ -64,6 +64,7 @@ class NBodyDomainStats(C.Structure):
         ("view_domain", C.c_int32),
         ("distributed", C.c_int32),
         ("exported_nodes", C.c_uint64 * 32),
+        ("export_ms", C.c_double * 32),
     ]
 
 

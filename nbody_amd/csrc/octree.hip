@@ -1523,8 +1523,10 @@ struct Domains {
     unsigned long long* imported = nullptr;  // [MAX_DOMAINS + 1] device
     uint64_t node_base[MAX_DOMAINS + 1] = {};
     hipEvent_t ev[MAX_DOMAINS + 3][2] = {};
+    hipEvent_t ev_export[MAX_DOMAINS][2] = {};  // choosing and packing a domain's export
     nbody_domain_stats_t stats{};
     // essential-tree exchange: what a domain hands to the others instead of its whole tree
+    bool export_timed[MAX_DOMAINS] = {};
     int view = -1;                    // >= 0: the merged tree is assembled as that domain's GPU would hold it
     uint8_t* let_flags = nullptr;     // [let_cap] per node of the exporting domain's tree: exported
     uint32_t* let_newid = nullptr;    // [let_cap] ... and its index among the exported nodes
@@ -1926,6 +1928,9 @@ static void domains_free(Octree* T) {
     for (auto& pair : Dm->ev)
         for (hipEvent_t e : pair)
             if (e) (void)hipEventDestroy(e);
+    for (auto& pair : Dm->ev_export)
+        for (hipEvent_t e : pair)
+            if (e) (void)hipEventDestroy(e);
     delete Dm;
     T->dom = nullptr;
 }
@@ -1981,6 +1986,9 @@ int nb_tree_set_domains(nbody_ctx* ctx, uint32_t domains, uint32_t top_levels) {
     if (e == hipSuccess) e = hipMalloc(&Dm->let_counts, 2 * MAX_DOMAINS * sizeof(uint32_t));
     if (e == hipSuccess) e = hipHostMalloc(&Dm->h_let_counts, 2 * MAX_DOMAINS * sizeof(uint32_t), hipHostMallocDefault);
     for (auto& pair : Dm->ev)
+        for (hipEvent_t& ev : pair)
+            if (e == hipSuccess) e = hipEventCreate(&ev);
+    for (auto& pair : Dm->ev_export)
         for (hipEvent_t& ev : pair)
             if (e == hipSuccess) e = hipEventCreate(&ev);
     if (e != hipSuccess) {
@@ -2168,7 +2176,9 @@ static int let_export(nbody_ctx* ctx, Octree* T, uint32_t k) {
     hipStream_t st = ctx->stream;
     uint32_t* counts = Dm->let_counts + 2 * k;
     NB_HIP(ctx, hipMemsetAsync(counts, 0, 2 * sizeof(uint32_t), st));
+    Dm->export_timed[k] = false;
     if (Dm->h_off[k + 1] == Dm->h_off[k]) return NBODY_OK;
+    NB_HIP(ctx, hipEventRecord(Dm->ev_export[k][0], st));
     const uint32_t n_nodes = (uint32_t)Tk->n_nodes, mark0 = Tk->h_lvl_start[Dm->L], lo_id = Tk->h_lvl_start[Dm->L + 1];
     if (int r = let_reserve(ctx, Dm, n_nodes)) return r;
     NB_HIP(ctx, hipMemsetAsync(Dm->let_flags, 0, n_nodes, st));
@@ -2185,7 +2195,10 @@ static int let_export(nbody_ctx* ctx, Octree* T, uint32_t k) {
                            lo_id, n_nodes, Dm->send_nodes, Dm->send_range, (uint32_t)Dm->send_cap);
     }
     NB_HIP(ctx, hipGetLastError());
-    return let_entries(ctx, T, k, true, Dm->send_entries, counts + 1);
+    if (int r = let_entries(ctx, T, k, true, Dm->send_entries, counts + 1)) return r;
+    NB_HIP(ctx, hipEventRecord(Dm->ev_export[k][1], st));
+    Dm->export_timed[k] = true;
+    return NBODY_OK;
 }
 
 static int let_box(nbody_ctx* ctx, Octree* T, uint32_t k) {
@@ -2327,6 +2340,7 @@ int nb_tree_forces_distributed(nbody_ctx* ctx, const float4* posm_in, const floa
     const uint32_t off = Dm->h_off[self], nk = Dm->h_off[self + 1] - off;
     if (int r = domain_build_one(ctx, T, self, posm_in)) return r;
     Octree* Ts = Dm->tree[self];
+    NB_HIP(ctx, hipEventRecord(Dm->ev[MAX_DOMAINS + 1][0], st));
     // where everybody's bodies are, what everybody exports
     if (int r = let_box(ctx, T, self)) return r;
     if (int r = nb_comm_allgather_inplace(ctx, Dm->boxes, (size_t)LET_BOXES * sizeof(LetBox))) return r;
@@ -2371,6 +2385,7 @@ int nb_tree_forces_distributed(nbody_ctx* ctx, const float4* posm_in, const floa
         if (m != sent) return nb_fail(ctx, NBODY_ERR_STATE, "domain build: a domain's entries changed between export and use");
     }
     if (int r = domains_top(ctx, T, (uint32_t)e0[G])) return r;
+    NB_HIP(ctx, hipEventRecord(Dm->ev[MAX_DOMAINS + 1][1], st));
     if (int r = check_err_flag(ctx, T, "distributed octree build")) return r;  // (the host has just waited for the top tree's level sizes anyway)
     nb_time_end(ctx, 2);
     Dm->stats.domains = G;
@@ -2425,7 +2440,14 @@ int nb_tree_domain_stats(nbody_ctx* ctx, nbody_domain_stats_t* out) {
         (void)hipGetLastError();  // (events of a part that did not run in the last build, e.g. another rank's domain)
         return 0.0;
     };
-    for (uint32_t k = 0; k < Dm->G; ++k) Dm->stats.build_ms[k] = ms((int)k);
+    for (uint32_t k = 0; k < Dm->G; ++k) {
+        Dm->stats.build_ms[k] = ms((int)k);
+        float t = 0.0f;
+        const bool timed = (Dm->stats.view_domain >= 0 || Dm->stats.distributed) && Dm->export_timed[k] &&
+                           hipEventElapsedTime(&t, Dm->ev_export[k][0], Dm->ev_export[k][1]) == hipSuccess;
+        if (!timed) (void)hipGetLastError();
+        Dm->stats.export_ms[k] = timed ? (double)t : 0.0;
+    }
     Dm->stats.partition_ms = ms(MAX_DOMAINS);
     Dm->stats.merge_ms = ms(MAX_DOMAINS + 1);
     *out = Dm->stats;

@@ -242,7 +242,7 @@ class NBodySim:
         st = _lib.NBodyDomainStats()
         self._ck(self.lib.nbody_bh_domain_stats(self.h, C.byref(st)))
         g = st.domains
-        per_domain = ("bodies", "nodes", "imported_nodes", "build_ms", "exported_nodes")
+        per_domain = ("bodies", "nodes", "imported_nodes", "build_ms", "exported_nodes", "export_ms")
         out = {f: getattr(st, f) for f, _ in _lib.NBodyDomainStats._fields_ if f not in per_domain}
         for f in per_domain:
             out[f] = list(getattr(st, f))[:g]

@@ -106,6 +106,7 @@ pub struct nbody_domain_stats_t {
     pub view_domain: i32,
     pub distributed: i32,
     pub exported_nodes: [u64; 32],
+    pub export_ms: [f64; 32],
 }
 
 #[repr(C)]

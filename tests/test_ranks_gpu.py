@@ -102,6 +102,16 @@ def test_barnes_hut_domains_exchange_essential_trees(tmp_path, ranks, n, law, da
     assert np.array_equal(one, many)
 
 
+def test_barnes_hut_domains_over_a_long_run(tmp_path):
+    """A cold sphere collapses and rebounds over 300 frames: the domains' populations and shapes change, bodies
+    reach the clamp; four ranks, each with its own domain's tree and the others' exports, stay on the
+    one-rank run's bits."""
+    args = ["--mode", "bh", "--law", "plummer", "--dataset", "plummer", "--n", "20011", "--frames", "300", "--seed", "3"]
+    one, _ = run(tmp_path, "one", 1, args)
+    many, _ = run(tmp_path, "d4", 4, args + ["--domains", "2"])
+    assert np.isfinite(one).all() and np.array_equal(one, many)
+
+
 def test_one_rank_with_domains_is_the_one_tree(tmp_path):
     args = ["--mode", "bh", "--n", "40000", "--frames", "3", "--seed", "4"]
     one, _ = run(tmp_path, "one", 1, args)

@@ -411,6 +411,30 @@ def main():
                 acc_ = s_.accel_bh()
                 c_ = s_.counters()
                 res[label] = (bms, acc_, c_, s_.bh_domain_stats() if g else None)
+                if g:
+                    # one rank's part of a distributed step, rehearsed for domain 0: the merged tree holds its own
+                    # tree and only what the other domains would send it (their essential-tree exports)
+                    s_.set_counting(False)
+                    s_.bh_set_domain_view(0)
+                    s_.build_octree()
+                    vs = s_.bh_domain_stats()
+                    n0 = vs["bodies"][0]
+                    _, _, order_ = s_.morton_keys(with_depth=False)
+                    mine_ = order_[:n0]
+                    acc_v = s_.accel_bh()
+                    s_.set_kernel_timing(True)
+                    s_.bh_forces_ranked(0, n0)
+                    s_.kernel_time(bh=True)
+                    for _ in range(2):
+                        s_.bh_forces_ranked(0, n0)
+                    wms, _ = s_.kernel_time(bh=True)
+                    vs = s_.bh_domain_stats()
+                    ex = [vs["export_ms"][k] for k in range(1, g) if vs["bodies"][k]]
+                    view = {"domain": 0, "bodies": n0, "own_nodes": vs["nodes"][0], "exported_by_others": vs["exported_nodes"],
+                            "received_MB_per_step": sum(vs["exported_nodes"]) * 36 / 1e6, "merged_nodes": vs["merged_nodes"],
+                            "own_build_ms": vs["build_ms"][0], "export_ms_each": float(np.mean(ex)) if ex else 0.0,
+                            "assemble_ms": vs["merge_ms"] - float(np.sum(ex)), "own_walk_ms": wms,
+                            "its_bodies_bit_equal_to_one_tree": bool(np.array_equal(acc_v[mine_], res["one_tree"][1][mine_]))}
         (b0, a0, c0, _), (b1, a1, c1, st) = res["one_tree"], res["domains"]
         same = bool(np.array_equal(a0, a1)) and all(c0[k] == c1[k] for k in
                                                      ("bh_node_visits", "bh_leaf_interactions", "bh_aggregate_interactions"))
@@ -419,9 +443,11 @@ def main():
                 "partition_ms": st["partition_ms"], "merge_ms": st["merge_ms"], "bodies": st["bodies"],
                 "top_nodes": st["top_nodes"], "merged_nodes": st["merged_nodes"], "one_tree_nodes": c0["octree_nodes"],
                 "imported_nodes": st["imported_nodes"], "imported_MB_per_step": [x * 36 / 1e6 for x in st["imported_nodes"]],
-                "results_identical_to_one_tree": same,
+                "results_identical_to_one_tree": same, "essential_tree_view": view,
                 "note": "logical domains on ONE GPU, built one after the other; per_domain_build_ms is each domain's own "
-                        "gather + build, i.e. what a GPU holding only that domain would spend (projected, not a multi-GPU run)"}
+                        "gather + build, i.e. what a GPU holding only that domain would spend (projected, not a multi-GPU run); "
+                        "essential_tree_view: one rank's part of the distributed step (nbody_step_bh with a communicator), "
+                        "rehearsed on this GPU with nbody_bh_set_domain_view"}
 
     def extra(key, fn):
         """An extra leg must not cost the headline line.  (With several ranks a failure cannot be

@@ -1510,6 +1510,7 @@ struct Domains {
     Octree* tree[MAX_DOMAINS] = {};
     Octree* top = nullptr;
     uint32_t top_cap = 0, top_node_cap = 0;
+    uint64_t share = 0;              // bodies a domain's tree is first given room for
     uint32_t* n_entries = nullptr;   // device counter, and its pinned copy
     uint32_t* h_entries = nullptr;
     float4* e_posm = nullptr;
@@ -1995,15 +1996,9 @@ int nb_tree_set_domains(nbody_ctx* ctx, uint32_t domains, uint32_t top_levels) {
         (void)hipGetLastError();
         return fail(NBODY_ERR_NOMEM, "nbody_bh_set_domains: out of device memory");
     }
-    // the domains' trees: room for a third more than an even share (domains are runs of whole cells)
-    const uint64_t share = std::min<uint64_t>(n, n / domains + n / (3 * domains) + 4096);
-    for (uint32_t k = 0; k < domains; ++k) {
-        Dm->tree[k] = new Octree;
-        if (int r = tree_alloc(ctx, Dm->tree[k], share, T->D)) {
-            domains_free(T);
-            return r;
-        }
-    }
+    // the domains' trees are made when a domain is first built here (a rank of a distributed run builds one
+    // only), with room for a third more than an even share (domains are runs of whole cells)
+    Dm->share = std::min<uint64_t>(n, n / domains + n / (3 * domains) + 4096);
     Dm->top = new Octree;
     if (int r = tree_alloc(ctx, Dm->top, Dm->top_cap, top_levels)) {
         domains_free(T);
@@ -2049,11 +2044,10 @@ static int domain_build_one(nbody_ctx* ctx, Octree* T, uint32_t k, const float4*
     Dm->stats.nodes[k] = 0;
     NB_HIP(ctx, hipEventRecord(Dm->ev[k][0], st));
     if (nk > 0) {
-        if (nk > Tk->n_cap) {  // a domain grown past its room: new arrays, with room to spare
-            const uint32_t D = Tk->D;
+        if (!Tk || nk > Tk->n_cap) {  // first use, or a domain grown past its room: new arrays, with room to spare
             tree_free(Tk);
             Dm->tree[k] = Tk = new Octree;
-            if (int r = tree_alloc(ctx, Tk, (uint64_t)nk + nk / 4 + 4096, D)) return r;
+            if (int r = tree_alloc(ctx, Tk, std::max<uint64_t>(Dm->share, (uint64_t)nk + nk / 4 + 4096), T->D)) return r;
         }
         hipLaunchKernelGGL(k_gather_bodies, dim3((nk + 255) / 256), dim3(256), 0, st, posm_in, Dm->dval[1] + off, nk,
                            Dm->posm_k + off);
@@ -2204,8 +2198,10 @@ static int let_export(nbody_ctx* ctx, Octree* T, uint32_t k) {
 static int let_box(nbody_ctx* ctx, Octree* T, uint32_t k) {
     Domains* Dm = T->dom;
     Octree* Tk = Dm->tree[k];
-    hipLaunchKernelGGL(k_let_box, dim3(1), dim3(128), 0, ctx->stream, Tk->nodes, Tk->bmin, Tk->bmax, Tk->lvl_start,
-                       Dm->h_off[k + 1] - Dm->h_off[k], Dm->boxes + (size_t)k * LET_BOXES);
+    const uint32_t bodies = Tk ? Dm->h_off[k + 1] - Dm->h_off[k] : 0u;  // (no tree: the domain has never held a body here)
+    hipLaunchKernelGGL(k_let_box, dim3(1), dim3(128), 0, ctx->stream, Tk ? Tk->nodes : (const QNode*)nullptr,
+                       Tk ? Tk->bmin : (const float4*)nullptr, Tk ? Tk->bmax : (const float4*)nullptr,
+                       Tk ? Tk->lvl_start : (const uint32_t*)nullptr, bodies, Dm->boxes + (size_t)k * LET_BOXES);
     NB_HIP(ctx, hipGetLastError());
     return NBODY_OK;
 }
@@ -2331,6 +2327,15 @@ int nb_tree_forces_distributed(nbody_ctx* ctx, const float4* posm_in, const floa
     if (!Dm->acc_grouped) NB_HIP(ctx, hipMalloc(&Dm->acc_grouped, (size_t)n * sizeof(float4)));
     const bool need_vel = ctx->cfg.law == NBODY_LAW_WGSL_BIAS;
     if (need_vel && !Dm->vel_k) NB_HIP(ctx, hipMalloc(&Dm->vel_k, (size_t)n * sizeof(float4)));
+    struct BuildTimer {  // the build's time ends where the build ends, also when it fails
+        nbody_ctx* ctx;
+        bool open = true;
+        void end() {
+            if (open) nb_time_end(ctx, 2);
+            open = false;
+        }
+        ~BuildTimer() { end(); }
+    } timer{ctx};
     nb_time_begin(ctx, 2);
     if (int r = domains_partition(ctx, T, posm_in)) return r;
     for (uint32_t k = 0; k < G; ++k) {
@@ -2387,7 +2392,7 @@ int nb_tree_forces_distributed(nbody_ctx* ctx, const float4* posm_in, const floa
     if (int r = domains_top(ctx, T, (uint32_t)e0[G])) return r;
     NB_HIP(ctx, hipEventRecord(Dm->ev[MAX_DOMAINS + 1][1], st));
     if (int r = check_err_flag(ctx, T, "distributed octree build")) return r;  // (the host has just waited for the top tree's level sizes anyway)
-    nb_time_end(ctx, 2);
+    timer.end();
     Dm->stats.domains = G;
     Dm->stats.top_levels = Dm->L;
     Dm->stats.merged_nodes = base[G] - Dm->top_node_cap + Dm->top->n_nodes;

@@ -110,6 +110,10 @@ def main():
     ap.add_argument("--bh-balance-every", type=int, default=0,
                     help="Barnes-Hut legs on several GPUs: every K steps move the ranks' runs of the sorted order after "
                          "their measured traversal times (0: equal runs; a centred Plummer sphere is balanced as it is)")
+    ap.add_argument("--bh-domains", type=int, default=0,
+                    help="with --comm library and several GPUs: Barnes-Hut with one domain per rank, each rank building "
+                         "its own domain's octree and the ranks exchanging essential trees; the value is the depth of the "
+                         "cells the bodies are dealt by (5 at N = 16M).  0: the replicated tree")
     ap.add_argument("--comm", default="torch", choices=["torch", "library"],
                     help="who runs the per-step exchange on several GPUs: torch.distributed collectives issued from "
                          "Python (default), or the library's own RCCL communicator (nbody_comm_init)")
@@ -302,6 +306,9 @@ def main():
         be.upload(m_, p_, v_)
         sim = ShardedSim(be, nbodies, rank, world, bh_balance_every=args.bh_balance_every,
                          library_comm=args.comm == "library")
+        distributed = bool(args.bh_domains) and world > 1 and args.comm == "library"
+        if distributed:
+            be.sim.bh_set_domains(world, args.bh_domains)
         sim.step_bh(2)
         be.sim.set_counting(True)                        # counting build of the traversal kernel, own targets only
         if world == 1:
@@ -366,6 +373,7 @@ def main():
                              "instruction sequence takes alone (no memory, 6-8 wavefronts per SIMD: "
                              "profiles/r02_ubench_walkmix.txt, sequence A) / (1,024 SIMDs x the nominal clock)"}
         return {"n_bodies": nbodies, "n_gpus": world, "law": law_name,
+                "tree": "one domain per rank, essential trees exchanged" if distributed else "replicated" if world > 1 else "one",
                 "ranks_hold_identical_positions": same, "theta": 0.5, "max_depth": 16, "steps": bsteps,
                 "steps_per_s": bsteps / bdt, "ms_per_step": bdt / bsteps * 1e3, "walk_kernel_ms": wms,
                 "build_ms": bms,

@@ -107,8 +107,9 @@ int run_rank(const Options& o, int rank, const std::string& id_path) {
         if ((rc = nbody_comm_init(ctx, id, rank, o.ranks))) return die(ctx, "nbody_comm_init", rc);
     }
     if ((rc = nbody_upload(ctx, masses.data(), pos.data(), nullptr, nullptr))) return die(ctx, "nbody_upload", rc);
-    if (o.domains > 0 && (rc = nbody_bh_set_domains(ctx, o.ranks > 1 ? (uint32_t)o.ranks : 8u, (uint32_t)o.domains)))
-        return die(ctx, "nbody_bh_set_domains", rc);
+    // one domain per rank; without a communicator, 8 domains on the one GPU
+    const uint32_t n_domains = o.domains > 0 ? ((o.ranks > 1 || o.force_comm) ? (uint32_t)o.ranks : 8u) : 0u;
+    if (n_domains >= 2 && (rc = nbody_bh_set_domains(ctx, n_domains, (uint32_t)o.domains))) return die(ctx, "nbody_bh_set_domains", rc);
     std::FILE* out = nullptr;
     uint32_t dumped = 0;
     if (rank == 0 && !o.dump.empty()) {
@@ -139,7 +140,7 @@ int run_rank(const Options& o, int rank, const std::string& id_path) {
         std::printf("%s: n=%llu ranks=%d frames=%d  %.3f ms/frame  %.1f frames/s  octree nodes (last) %llu  all-pairs path %llu\n",
                     o.mode.c_str(), (unsigned long long)n, o.ranks, o.frames, 1e3 * s / o.frames, o.frames / s,
                     (unsigned long long)c.octree_nodes, (unsigned long long)c.allpairs_path);
-    if (o.domains > 0 && rank == 0) {
+    if (n_domains >= 2 && rank == 0) {
         nbody_domain_stats_t st;
         if ((rc = nbody_bh_domain_stats(ctx, &st))) return die(ctx, "nbody_bh_domain_stats", rc);
         unsigned long long received = 0;

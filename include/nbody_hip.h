@@ -95,7 +95,9 @@ typedef struct nbody_config {
     float world;           /* 250.0: octree root cube [0,world]^3 and the Barnes-Hut clamp box */
     uint32_t max_depth;    /* 1..16: depth cap of src/octree_maxdepth.rs.  0: the uncapped builder of src/octree.rs
                               (dormant in the reference), reproduced while no two bodies share a level-16
-                              cell (else the build fails): no leaf lists; nbody_download_octree then writes
+                              cell (else the build fails) and no body has mass 0 (nbody_upload refuses:
+                              src/octree.rs:49 takes a massless node for an empty one): no leaf lists;
+                              nbody_download_octree then writes
                               is_leaf at offset 84 and, on the root, max_depth at offset 88 (src/octree.rs:5-15,36) */
     int32_t leaflist_mode; /* 0: literal src/octree_maxdepth.rs:123-133 (a k-body list holds the k-1 prefix
                               aggregates); 1: every body of the cell is a list member */

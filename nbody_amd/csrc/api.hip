@@ -258,6 +258,13 @@ int nbody_upload(nbody_ctx* ctx, const float* host_masses, const float* host_pos
         ctx->mass0 = host_masses[0];
         ctx->uniform_mass = true;
         for (uint64_t i = 1; i < ctx->n && ctx->uniform_mass; ++i) ctx->uniform_mass = host_masses[i] == ctx->mass0;
+        if (ctx->cfg.max_depth == 0) {
+            // src/octree.rs:49 takes a node of total mass 0 for an EMPTY one: the next body inserted there
+            // replaces a massless body instead of splitting the cell.  That is not reproduced; refused instead.
+            for (uint64_t i = 0; i < ctx->n; ++i)
+                if (host_masses[i] == 0.0f)
+                    return nb_fail(ctx, NBODY_ERR_INVALID, "nbody_upload: max_depth 0 (the octree.rs builder) does not take bodies of mass 0");
+        }
         r = upload_set(ctx, 0, host_masses, host_pos16, host_vel16, host_acc16, true);
         if (r) return r;
         // second set: zeros (src/nbody_cpu.rs:58-60), mass kept in the pad lane

@@ -454,10 +454,16 @@ void orc_step_wgsl_allpairs(int law, int64_t n, int nsteps, const float* masses,
 // pos16: 16-byte stride.  nodes_out: capacity cap_nodes (96 B each).  body_leaf/body_depth: per
 // body, the node index and depth of its leaf (LEAFBODY node, or the LEAFLIST node that holds it)
 // in the finished tree.  Returns the node count, or -1 if cap_nodes is too small, -2 if the
-// unbounded variant did not terminate (coincident bodies).  *max_depth_out: octree.rs:36 value.
+// unbounded variant did not terminate (coincident bodies), -3 if variant 1 is given a body of mass 0:
+// src/octree.rs:49 recognises an empty node by `total_mass == 0.0`, so a massless body is REPLACED by the
+// next body that reaches its node; this restatement tells empty nodes by their type and does not
+// reproduce that.  *max_depth_out: octree.rs:36 value.
 int64_t orc_build_octree(int variant, int64_t n, const float* pos16, const float* masses, float world,
                          uint32_t max_depth, int leaflist_mode, Node96* nodes_out, int64_t cap_nodes,
                          uint32_t* body_leaf, uint8_t* body_depth, uint32_t* max_depth_out) {
+    if (variant == 1)
+        for (int64_t i = 0; i < n; ++i)
+            if (masses[i] == 0.0f) return -3;
     Builder b;
     b.max_depth_cap = (variant == 0) ? max_depth : 0xffffffffu;
     b.leaflist_mode = leaflist_mode;

@@ -122,6 +122,8 @@ def build_octree(pos16, masses, variant=0, world=250.0, max_depth=16, leaflist_m
         if cnt == -1:
             cap *= 4
             continue
+        if cnt == -3:
+            raise ValueError("the octree.rs variant is not restated for bodies of mass 0 (src/octree.rs:49 takes their node for an empty one)")
         if cnt < 0:
             raise RuntimeError(f"oracle octree build failed: {cnt}")
         # byte-wise copy: numpy does not promise to copy the padding bytes of a structured dtype

@@ -597,3 +597,22 @@ def test_uncapped_variant_refuses_what_16_levels_cannot_separate(orc):
         sim.upload(m, pos)
         with pytest.raises(nb.NBodyError, match="level-16"):
             sim.build_octree()
+
+
+def test_uncapped_variant_refuses_massless_bodies(orc):
+    """src/octree.rs:49 takes a node of total mass 0 for an empty one (a massless body is replaced by the next
+    body to reach its node); neither the library nor the oracle reproduces that: both refuse.  The capped
+    builder tells empty nodes by their type and takes massless bodies."""
+    import nbody_amd as nb
+    pos = p4([[10, 10, 10], [100, 40, 30], [200, 100, 50]])
+    m = np.array([1, 0, 2], np.float32)
+    with nb.NBodySim(3, max_depth=0) as sim:
+        with pytest.raises(nb.NBodyError, match="mass 0"):
+            sim.upload(m, pos)
+    with pytest.raises(ValueError):
+        orc.build_octree(pos, m, variant=1)
+    with nb.NBodySim(3) as sim:
+        sim.upload(m, pos)
+        sim.build_octree()
+        ref, _, _, _ = orc.build_octree(pos, m, variant=0)
+        assert sim.counters()["octree_nodes"] == len(ref)

@@ -166,6 +166,17 @@ def test_unbounded_tree_max_depth(orc):
     assert sorted(int(x) for x in nodes["node_type"]) == [0, 0, 0, 0, 1, 1]   # is_leaf flags
 
 
+def test_unbounded_tree_refuses_massless_bodies(orc):
+    # src/octree.rs:49 tells an empty node by total_mass == 0.0, so a massless body would be replaced by
+    # the next one to reach its node: not restated, refused (the capped builder tells by node type and takes them)
+    pos = p4([[1, 1, 1], [20, 20, 20], [200, 30, 40]])
+    m = np.array([1, 0, 2], np.float32)
+    with pytest.raises(ValueError):
+        orc.build_octree(pos, m, variant=1)
+    nodes, _, _, _ = orc.build_octree(pos, m, variant=0)
+    assert np.isclose(nodes[0]["total_mass"], 3.0)
+
+
 def test_walk_theta_zero_equals_allpairs_and_order(orc):
     m, pos = orc.gen_refcube(300, seed=3)
     vel = np.zeros((300, 4), np.float32)

@@ -34,7 +34,7 @@ def run(tmp_path, tag, ranks, args, timeout=300):
     cmd = [EXE] + args + ["--report", "0", "--state", str(state)]
     if ranks > 1:
         env["NBODY_RCCL_LIB"] = TRANSPORT
-        env["NBODY_SHM_SLOT_MB"] = "4"      # small slots: the chunked path runs too
+        env["NBODY_SHM_SLOT_KB"] = "192"    # slots smaller than most messages: the chunked path runs too
         cmd += ["--ranks", str(ranks), "--devices", "1"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
     assert r.returncode == 0, r.stdout + r.stderr

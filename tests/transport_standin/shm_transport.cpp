@@ -48,7 +48,11 @@ struct Comm {
 
 constexpr double BARRIER_TIMEOUT_S = 180.0;
 
-size_t slot_bytes() {
+size_t slot_bytes() {  // NBODY_SHM_SLOT_KB (tests: slots far smaller than the messages, so that every exchange is chunked) or NBODY_SHM_SLOT_MB
+    if (const char* kb = std::getenv("NBODY_SHM_SLOT_KB")) {
+        const long v = std::atol(kb);
+        if (v > 0) return (size_t)v << 10;
+    }
     const char* mb = std::getenv("NBODY_SHM_SLOT_MB");
     const long v = mb ? std::atol(mb) : 0;
     return (size_t)(v > 0 ? v : 32) << 20;

@@ -108,6 +108,13 @@ def test_domains_are_refused_where_they_do_not_apply():
             sim.bh_set_domains(33, 3)
         with pytest.raises(nb.NBodyError):
             sim.bh_domain_stats()                             # nothing set
+        with pytest.raises(nb.NBodyError):
+            sim.bh_set_domain_view(0)                         # a view needs domains
+        sim.bh_set_domains(4, 3)
+        with pytest.raises(nb.NBodyError):
+            sim.bh_set_domain_view(4)                         # domains are 0..3
+        sim.bh_set_domain_view(3)
+        sim.bh_set_domain_view(-1)
 
 
 def test_domains_stay_bit_equal_over_a_long_run():
